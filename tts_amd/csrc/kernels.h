@@ -1,0 +1,103 @@
+// Kernel parameter blocks and launch prototypes shared by conv_mfma.hip, ops.hip, engine.hip.
+// Every activation is channel-first: x[b][c][t] at  x + b*bstride + c*pitch + t,  and every
+// sentence b has its own valid length  L_b = lmul*lens[b] + ladd  (lens = tokens per sentence
+// at token rate, frames per sentence at frame rate).  Positions t >= L_b hold garbage that no
+// kernel ever reads un-masked, so padding is bit-invisible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define K82_MAXTOK_P1 513   // 512 tokens + 1 (prefix-sum array of the alignment kernel)
+
+struct LenSpec {            // per-sentence valid length
+    const int* lens;        // device i32[B]; nullptr => every sentence has length ladd
+    int lmul, ladd;
+    __host__ __device__ int len(int b) const { return lens ? lmul * lens[b] + ladd : ladd; }
+};
+
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SNAKE = 2 };
+enum { TR_NONE = 0, TR_SCALE = 1, TR_NORM = 2 };
+enum { OACT_NONE = 0, OACT_GELU_NEW = 1 };
+
+// Implicit-GEMM Conv1d on v_mfma_f32_32x32x2_f32 (conv_mfma.hip).
+struct ConvP {
+    const float* x; long xbs; int xpitch;      // input  [B][cin_p][xpitch]
+    const float* w;                            // weights [taps][cin_p][cout_p] (tap-major, cout contiguous)
+    const float* bias;                         // [cout_p] or nullptr
+    float* y; long ybs; int ypitch;            // output (nullptr: accumulate only)
+    LenSpec lin, lout;                         // input / output valid lengths
+    int cin, cin_p, cout, cout_p, taps, dil, pad;
+    // input transform, applied to valid positions only (zero padding comes after it):
+    //   TR_SCALE: v = in_scale*x ; TR_NORM: v = ((x-mean)*rstd)*g + beta with norm[b*nstride+ci] = {mean,rstd,g,beta}
+    //   then ACT_LEAKY: v<0 ? slope*v : v ; ACT_SNAKE: v + inv_alpha*sin(alpha*v)^2
+    int tr; float in_scale; const float4* norm; int nstride;
+    int act; float slope; const float* alpha; const float* inv_alpha;
+    // epilogue: v = out_act(acc + bias) ; v = (v + res[t >> res_shift]) * out_scale ; y = v ; accbuf (+)= v*acc_scale
+    int out_act;
+    const float* res; long rbs; int rpitch; int res_shift;
+    float out_scale;
+    float* accbuf; long abs_; int apitch; int acc_init; float acc_scale;
+    // transposed-conv phase interleave: row m = r*up_cout + co is stored at y[co][up_s*t + r + up_off]
+    int up_s, up_cout_shift, up_off;
+    const unsigned* tapmask;                   // per 64-row M tile: bitmask of non-zero taps (nullptr: all)
+    int B, Lmax_out;                           // grid extents
+};
+void launch_conv(const ConvP& p, hipStream_t s);
+double conv_flops(const ConvP& p, const int* host_lens);   // algorithmic FLOPs of one launch
+
+// ---- ops.hip ---------------------------------------------------------------------------
+// AdaIN statistics: norm[b*nstride+c] = {mean, rstd, 1+gamma, beta} over t < L_b.
+void launch_adain_stats(const float* x, long xbs, int xpitch, LenSpec ls, int C, int B,
+                        const float* gb, int gbstride, int goff,   // gamma at gb[b*gbstride+goff+c], beta at +C
+                        float4* norm, int nstride, int Lmax, hipStream_t s);
+// gb[b][r] = W[r][:] . style[b][soff:soff+128] + bias[r]
+void launch_style_fc(const float* W, const float* bias, int rows, const float* ref_s, int soff,
+                     float* gb, int gbstride, int B, hipStream_t s);
+// LayerNorm over channels of [B][C][pitch] per (b,t): y = ((x+res)-mean)*rstd*w[c]+bias[c]  (w/bias per channel)
+// or AdaLN: (1+gamma_b[c])*xn + beta_b[c] when gb != nullptr.  Optional LeakyReLU afterwards.
+void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, int pitch, LenSpec ls,
+                           int C, int B, int Tmax, float eps, const float* w, const float* bias,
+                           const float* gb, int gbstride, int goff, float leaky, hipStream_t s);
+void launch_albert_embed(const int64_t* ids, int Tmax, const float* word, const float* pos, const float* type0,
+                         const float* lnw, const float* lnb, float eps, float* y, long ybs, int ypitch,
+                         LenSpec ls, int B, hipStream_t s);
+void launch_embed(const int64_t* ids, int Tmax, const float* emb, int C, float* y, long ybs, int ypitch,
+                  LenSpec ls, int B, hipStream_t s);
+// qkv [B][3*H*64][pitch] -> ctx [B][H*64][pitch]
+void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long cbs, int cpitch,
+                      LenSpec ls, int heads, int B, int Tmax, hipStream_t s);
+// BiLSTM recurrence, hidden 256.  gx [B][2048][pitch] (fwd gates i,f,g,o then reverse), whh [2][256(k)][256(j)][4]
+void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch,
+                 LenSpec ls, int B, hipStream_t s);
+// rows [r0, r0+n) of y get value v[b*vstride + voff + i] for t < L_b (style broadcast)
+void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
+                      LenSpec ls, int B, int Tmax, hipStream_t s);
+void launch_durations(const float* logits, long lbs, int lpitch, int ndur, const float* speed,
+                      const int* lens, int B, int Tmax, int* dur, float* raw, hipStream_t s);
+// idx[b][f] = token index of frame f ; nfr[b] = sum dur
+void launch_alignment(const int* dur, int Tmax, const int* lens, int B, int* idx, int ipitch, int* nfr, hipStream_t s);
+void launch_gather(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch, const int* nfr,
+                   float* y, long ybs, int ypitch, int B, int Fmax, hipStream_t s);
+// depthwise ConvTranspose1d k3 s2 p1 op1 over act(norm(x)) : [C][L] -> [C][2L]
+void launch_pool_up2(const float* x, long xbs, int xpitch, const float4* norm, int nstride, float slope,
+                     const float* w, const float* bias, float* y, long ybs, int ypitch, LenSpec ls,
+                     int C, int B, int Lmax, hipStream_t s);
+// Conv1d 1->1 k3 s2 p1 on a single row: y[f] = w0*x[2f-1]+w1*x[2f]+w2*x[2f+1]+b, f < F_b
+void launch_conv_k3s2(const float* x, long xbs, const float* w3b, float* y, long ybs, const int* nfr,
+                      int B, int Fmax, hipStream_t s);
+void launch_copy_rows(const float* x, long xbs, int xpitch, float* y, long ybs, int ypitch, int rows,
+                      LenSpec ls, int B, int Lmax, hipStream_t s);
+// harmonic source (source.hip)
+void launch_src_phase(const float* f0, long fbs, const int* nfr, int B, float* ph, long pbs, int ppitch, hipStream_t s);
+void launch_src_har(const float* f0, long fbs, const float* ph, long pbs, int ppitch, const int* nfr,
+                    const float* noise, const int64_t* noise_off, const uint64_t* seeds,
+                    const float* lin_w, const float* lin_b, float* har_src, long hbs, int B, int Fmax, hipStream_t s);
+// STFT n_fft 20 hop 5 (center, reflect) -> har [B][32][p1] (22 valid rows: 11 mag, 11 phase) and its
+// stride-6 polyphase image harp [B][144][p0]: harp[ci*6+r][q] = har[ci][6q+r-3]
+void launch_stft(const float* har_src, long hbs, const int* nfr, int B, int Fmax,
+                 float* har, long bs1, int p1, float* harp, long bs0, int p0, hipStream_t s);
+void launch_reflect_fix(float* y, long ybs, int ypitch, const float* xs, long xbs, int xpitch, int C, int B, hipStream_t s);
+// conv_post output [B][>=22][p1] -> audio: spec=exp(x[:11]), phase=sin(x[11:]), iSTFT n_fft 20 hop 5
+void launch_istft(const float* cp, long cbs, int cpitch, const int* nfr, int B, int Fmax,
+                  float* audio, const int64_t* aoff, hipStream_t s);
+void launch_pcm16(const float* src, int16_t* dst, int64_t n, hipStream_t s);

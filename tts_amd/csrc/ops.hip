@@ -1,0 +1,442 @@
+// Bandwidth- and latency-bound kernels around the MFMA conv: AdaIN statistics, LayerNorm,
+// embeddings, attention, the BiLSTM recurrence, durations/alignment/gather (length
+// regulation), the depthwise up-sampling pool and small copies.  All channel-first
+// (kernels.h).  64-wide wavefronts throughout; every reduction is deterministic (fixed
+// order, no float atomics) so two runs give identical bits.
+#include "kernels.h"
+
+#define DIVUP(a, b) (((a) + (b)-1) / (b))
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- AdaIN statistics (row a13)
+// One workgroup per (c, b) row: one coalesced float4 sweep, sums in fp64 (one-pass mean and
+// E[x^2] are exact enough in double: 53-bit accumulators over <= 2.5e5 fp32 samples).
+__global__ __launch_bounds__(256) void adain_stats_kernel(const float* x, long xbs, int xpitch, LenSpec ls, int C,
+                                                         const float* gb, int gbstride, int goff, float4* norm,
+                                                         int nstride) {
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int L = ls.len(b);
+    const float* xr = x + (long)b * xbs + (long)c * xpitch;
+    double s = 0.0, q = 0.0;
+    const int L4 = L >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    for (int i = tid; i < L4; i += 256) {
+        const float4 v = x4[i];
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int i = (L4 << 2) + tid; i < L; i += 256) {
+        const float v = xr[i];
+        s += v;
+        q += (double)v * v;
+    }
+    __shared__ double sh[8];
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) { sh[w] = s; sh[4 + w] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        s = sh[0] + sh[1] + sh[2] + sh[3];
+        q = sh[4] + sh[5] + sh[6] + sh[7];
+        const double mean = s / L;
+        double var = q / L - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float g = 1.0f + gb[(long)b * gbstride + goff + c];
+        const float be = gb[(long)b * gbstride + goff + C + c];
+        norm[(long)b * nstride + c] = make_float4((float)mean, rstd, g, be);
+    }
+}
+void launch_adain_stats(const float* x, long xbs, int xpitch, LenSpec ls, int C, int B, const float* gb,
+                        int gbstride, int goff, float4* norm, int nstride, int Lmax, hipStream_t s) {
+    (void)Lmax;
+    hipLaunchKernelGGL(adain_stats_kernel, dim3(C, B), dim3(256), 0, s, x, xbs, xpitch, ls, C, gb, gbstride, goff,
+                       norm, nstride);
+}
+
+// --------------------------------------------------------------------------- style FCs
+// One wave per output row: 128-long dot product, 2 elements per lane.
+__global__ __launch_bounds__(256) void style_fc_kernel(const float* W, const float* bias, int rows,
+                                                      const float* ref_s, int soff, float* gb, int gbstride) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* s = ref_s + (long)b * 256 + soff;
+    const float* w = W + (long)r * 128;
+    float a = w[lane] * s[lane] + w[lane + 64] * s[lane + 64];
+    a = wave_sumf(a);
+    if (lane == 0) gb[(long)b * gbstride + r] = a + bias[r];
+}
+void launch_style_fc(const float* W, const float* bias, int rows, const float* ref_s, int soff, float* gb,
+                     int gbstride, int B, hipStream_t s) {
+    hipLaunchKernelGGL(style_fc_kernel, dim3(DIVUP(rows, 4), B), dim3(256), 0, s, W, bias, rows, ref_s, soff, gb,
+                       gbstride);
+}
+
+// ------------------------------------------------------------- LayerNorm over channels
+// Thread per (b, t): the C channel values of one position are a strided column, adjacent
+// threads read adjacent t => coalesced.  Two-pass (mean, then centred variance).
+__global__ __launch_bounds__(64) void layernorm_cols_kernel(const float* x, const float* res, float* y, long bs,
+                                                           int pitch, LenSpec ls, int C, float eps, const float* w,
+                                                           const float* bias, const float* gb, int gbstride,
+                                                           int goff, float leaky) {
+    const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= ls.len(b)) return;
+    const float* xc = x + (long)b * bs + t;
+    const float* rc = res ? res + (long)b * bs + t : nullptr;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += xc[(long)c * pitch] + (rc ? rc[(long)c * pitch] : 0.f);
+    const float mean = s / C;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = xc[(long)c * pitch] + (rc ? rc[(long)c * pitch] : 0.f) - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(q / C + eps);
+    float* yc = y + (long)b * bs + t;
+    const float* g = gb ? gb + (long)b * gbstride + goff : nullptr;
+    for (int c = 0; c < C; ++c) {
+        float v = (xc[(long)c * pitch] + (rc ? rc[(long)c * pitch] : 0.f) - mean) * rstd;
+        if (g) v = (1.0f + g[c]) * v + g[C + c];
+        else v = v * w[c] + bias[c];
+        if (leaky != 1.0f) v = v < 0.f ? v * leaky : v;
+        yc[(long)c * pitch] = v;
+    }
+}
+void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, int pitch, LenSpec ls, int C,
+                           int B, int Tmax, float eps, const float* w, const float* bias, const float* gb,
+                           int gbstride, int goff, float leaky, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_cols_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, x, res, y, bs, pitch, ls, C,
+                       eps, w, bias, gb, gbstride, goff, leaky);
+}
+
+// ------------------------------------------------------------------------- embeddings
+__global__ __launch_bounds__(64) void albert_embed_kernel(const int64_t* ids, int Tmax, const float* word,
+                                                         const float* pos, const float* type0, const float* lnw,
+                                                         const float* lnb, float eps, float* y, long ybs, int ypitch,
+                                                         LenSpec ls) {
+    const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= ls.len(b)) return;
+    const float* wv = word + (long)ids[(long)b * Tmax + t] * 128;
+    const float* pv = pos + (long)t * 128;
+    float s = 0.f;
+    for (int c = 0; c < 128; ++c) s += (wv[c] + type0[c]) + pv[c];
+    const float mean = s / 128.f;
+    float q = 0.f;
+    for (int c = 0; c < 128; ++c) {
+        const float d = (wv[c] + type0[c]) + pv[c] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(q / 128.f + eps);
+    float* yc = y + (long)b * ybs + t;
+    for (int c = 0; c < 128; ++c) yc[(long)c * ypitch] = ((wv[c] + type0[c]) + pv[c] - mean) * rstd * lnw[c] + lnb[c];
+}
+void launch_albert_embed(const int64_t* ids, int Tmax, const float* word, const float* pos, const float* type0,
+                         const float* lnw, const float* lnb, float eps, float* y, long ybs, int ypitch, LenSpec ls,
+                         int B, hipStream_t s) {
+    hipLaunchKernelGGL(albert_embed_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, ids, Tmax, word, pos, type0,
+                       lnw, lnb, eps, y, ybs, ypitch, ls);
+}
+
+__global__ __launch_bounds__(64) void embed_kernel(const int64_t* ids, int Tmax, const float* emb, int C, float* y,
+                                                  long ybs, int ypitch, LenSpec ls) {
+    const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= ls.len(b)) return;
+    const float* e = emb + (long)ids[(long)b * Tmax + t] * C;
+    float* yc = y + (long)b * ybs + t;
+    for (int c = 0; c < C; ++c) yc[(long)c * ypitch] = e[c];
+}
+void launch_embed(const int64_t* ids, int Tmax, const float* emb, int C, float* y, long ybs, int ypitch, LenSpec ls,
+                  int B, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, ids, Tmax, emb, C, y, ybs, ypitch, ls);
+}
+
+// ------------------------------------------------------------------ attention (row a5)
+// One wave per (64 queries, head, sentence); lane = query.  K/V tiles of 64 keys go through
+// LDS ([d][key], rows coalesced from the channel-first qkv tensor); every lane reads the same
+// LDS word per (d, key) step => broadcast, no bank conflict.  Online softmax per 64-key tile.
+__global__ __launch_bounds__(64) void attention_kernel(const float* qkv, long qbs, int qpitch, float* ctx, long cbs,
+                                                      int cpitch, LenSpec ls, int heads) {
+    __shared__ float Ks[64 * 64];
+    __shared__ float Vs[64 * 64];
+    const int b = blockIdx.z, hd = blockIdx.y, lane = threadIdx.x;
+    const int T = ls.len(b);
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= T) return;
+    const int tq = q0 + lane;
+    const int HD = heads * 64;
+    const float* qb = qkv + (long)b * qbs + (long)(hd * 64) * qpitch;
+    const float* kb = qb + (long)HD * qpitch;
+    const float* vb = kb + (long)HD * qpitch;
+    float q[64], o[64];
+    const int tql = tq < T ? tq : T - 1;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+        q[d] = qb[(long)d * qpitch + tql] * 0.125f;
+        o[d] = 0.f;
+    }
+    float m = -1e30f, l = 0.f;
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        __syncthreads();
+        const int jj = j0 + lane;
+        for (int d = 0; d < 64; ++d) {
+            Ks[d * 64 + lane] = jj < T ? kb[(long)d * qpitch + jj] : 0.f;
+            Vs[d * 64 + lane] = jj < T ? vb[(long)d * qpitch + jj] : 0.f;
+        }
+        __syncthreads();
+        const int nk = min(64, T - j0);
+        float sc[64];
+        float tmax = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) a += q[d] * Ks[d * 64 + j];
+            sc[j] = j < nk ? a : -1e30f;
+            tmax = fmaxf(tmax, sc[j]);
+        }
+        const float mn = fmaxf(m, tmax);
+        const float corr = expf(m - mn);
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] *= corr;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const float pj = j < nk ? expf(sc[j] - mn) : 0.f;
+            l += pj;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) o[d] += pj * Vs[d * 64 + j];
+        }
+        m = mn;
+    }
+    if (tq < T) {
+        const float inv = 1.0f / l;
+        float* cb = ctx + (long)b * cbs + (long)(hd * 64) * cpitch + tq;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) cb[(long)d * cpitch] = o[d] * inv;
+    }
+}
+void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long cbs, int cpitch, LenSpec ls,
+                      int heads, int B, int Tmax, hipStream_t s) {
+    hipLaunchKernelGGL(attention_kernel, dim3(DIVUP(Tmax, 64), heads, B), dim3(64), 0, s, qkv, qbs, qpitch, ctx, cbs,
+                       cpitch, ls, heads);
+}
+
+// ------------------------------------------------------ BiLSTM recurrence (rows a7, a8, a10, a11)
+// One workgroup per (direction, sentence), thread j owns hidden unit j: its 4 gate rows of
+// W_hh stream from L2 as one float4 per k (layout [dir][k][j][i,f,g,o], 1 MB per direction,
+// L2-resident and shared by all sentences), h is double-buffered in LDS (one barrier per
+// step), c stays in a register.  fp32 throughout: the duration branch must round exactly.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
+                                                  long ybs, int ypitch, LenSpec ls) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][256];
+    const int dir = blockIdx.x, b = blockIdx.y, j = threadIdx.x;
+    const int T = ls.len(b);
+    const float4* W = reinterpret_cast<const float4*>(whh) + (long)dir * 256 * 256 + j;
+    const float* g0 = gx + (long)b * gbs + (long)(dir * 1024 + j) * gpitch;
+    const long gs = (long)256 * gpitch;
+    float* yo = y + (long)b * ybs + (long)(dir * 256 + j) * ypitch;
+    float c = 0.f;
+    hbuf[0][j] = 0.f;
+    __syncthreads();
+    int p = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        float ai = g0[t], af = g0[gs + t], ag = g0[2 * gs + t], ao = g0[3 * gs + t];
+        const float4* h4 = reinterpret_cast<const float4*>(hbuf[p]);
+#pragma unroll 4
+        for (int k4 = 0; k4 < 64; ++k4) {
+            const float4 hv = h4[k4];
+            const float4 w0 = W[(long)(4 * k4 + 0) * 256];
+            const float4 w1 = W[(long)(4 * k4 + 1) * 256];
+            const float4 w2 = W[(long)(4 * k4 + 2) * 256];
+            const float4 w3 = W[(long)(4 * k4 + 3) * 256];
+            ai += w0.x * hv.x; af += w0.y * hv.x; ag += w0.z * hv.x; ao += w0.w * hv.x;
+            ai += w1.x * hv.y; af += w1.y * hv.y; ag += w1.z * hv.y; ao += w1.w * hv.y;
+            ai += w2.x * hv.z; af += w2.y * hv.z; ag += w2.z * hv.z; ao += w2.w * hv.z;
+            ai += w3.x * hv.w; af += w3.y * hv.w; ag += w3.z * hv.w; ao += w3.w * hv.w;
+        }
+        const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanhf(ag), og = sigmoidf_(ao);
+        c = fg * c + ig * gg;
+        const float hn = og * tanhf(c);
+        hbuf[p ^ 1][j] = hn;
+        yo[t] = hn;
+        __syncthreads();
+        p ^= 1;
+    }
+}
+void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
+                 int B, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(256), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
+}
+
+// ------------------------------------------------------------------------ small helpers
+__global__ void fill_rows_kernel(float* y, long ybs, int ypitch, int r0, const float* v, int vstride, int voff,
+                                 LenSpec ls) {
+    const int b = blockIdx.z, i = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ls.len(b)) return;
+    y[(long)b * ybs + (long)(r0 + i) * ypitch + t] = v[(long)b * vstride + voff + i];
+}
+void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
+                      LenSpec ls, int B, int Tmax, hipStream_t s) {
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(DIVUP(Tmax, 256), n, B), dim3(256), 0, s, y, ybs, ypitch, r0, v,
+                       vstride, voff, ls);
+}
+
+__global__ void copy_rows_kernel(const float* x, long xbs, int xpitch, float* y, long ybs, int ypitch, LenSpec ls) {
+    const int b = blockIdx.z, r = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ls.len(b)) return;
+    y[(long)b * ybs + (long)r * ypitch + t] = x[(long)b * xbs + (long)r * xpitch + t];
+}
+void launch_copy_rows(const float* x, long xbs, int xpitch, float* y, long ybs, int ypitch, int rows, LenSpec ls,
+                      int B, int Lmax, hipStream_t s) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(DIVUP(Lmax, 256), rows, B), dim3(256), 0, s, x, xbs, xpitch, y, ybs,
+                       ypitch, ls);
+}
+
+// ----------------------------------------------------------------- durations (row a8)
+// duration = sum_k sigmoid(logit_k) / speed ; round half-to-even ; clamp(min=1).  The 50
+// sigmoids are rounded to fp32 one by one (as torch does), summed in fp64 and rounded once,
+// so the sum is the correctly rounded value of what any fp32 summation order approximates.
+__global__ void durations_kernel(const float* logits, long lbs, int lpitch, int ndur, const float* speed,
+                                 const int* lens, int Tmax, int* dur, float* raw) {
+    const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= Tmax) return;
+    int d = 0;
+    float r = 0.f;
+    if (t < lens[b]) {
+        const float* lg = logits + (long)b * lbs + t;
+        double s = 0.0;
+        for (int k = 0; k < ndur; ++k) s += (double)sigmoidf_(lg[(long)k * lpitch]);
+        r = __fdiv_rn((float)s, speed[b]);
+        const float rr = rintf(r);
+        d = rr < 1.0f ? 1 : (int)rr;
+    }
+    dur[(long)b * Tmax + t] = d;
+    raw[(long)b * Tmax + t] = r;
+}
+void launch_durations(const float* logits, long lbs, int lpitch, int ndur, const float* speed, const int* lens,
+                      int B, int Tmax, int* dur, float* raw, hipStream_t s) {
+    hipLaunchKernelGGL(durations_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, logits, lbs, lpitch, ndur, speed,
+                       lens, Tmax, dur, raw);
+}
+
+// -------------------------------------------------------- alignment + gather (row a9)
+// The reference builds a one-hot [T, F] matrix and multiplies; that is a gather.
+__global__ __launch_bounds__(256) void alignment_kernel(const int* dur, int Tmax, const int* lens, int* idx,
+                                                       int ipitch, int* nfr) {
+    __shared__ int cum[K82_MAXTOK_P1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int T = lens[b];
+    const int* d = dur + (long)b * Tmax;
+    if (tid == 0) {
+        int a = 0;
+        for (int t = 0; t < T; ++t) { cum[t] = a; a += d[t]; }
+        cum[T] = a;
+        nfr[b] = a;
+    }
+    __syncthreads();
+    int* ib = idx + (long)b * ipitch;
+    for (int t = tid; t < T; t += 256) {
+        const int s = cum[t], e = cum[t + 1];
+        for (int f = s; f < e && f < ipitch; ++f) ib[f] = t;
+    }
+}
+void launch_alignment(const int* dur, int Tmax, const int* lens, int B, int* idx, int ipitch, int* nfr,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(alignment_kernel, dim3(B), dim3(256), 0, s, dur, Tmax, lens, idx, ipitch, nfr);
+}
+
+__global__ void gather_kernel(const float* x, long xbs, int xpitch, const int* idx, int ipitch, const int* nfr,
+                              float* y, long ybs, int ypitch) {
+    const int b = blockIdx.z, c = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= nfr[b]) return;
+    y[(long)b * ybs + (long)c * ypitch + f] = x[(long)b * xbs + (long)c * xpitch + idx[(long)b * ipitch + f]];
+}
+void launch_gather(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch, const int* nfr, float* y,
+                   long ybs, int ypitch, int B, int Fmax, hipStream_t s) {
+    hipLaunchKernelGGL(gather_kernel, dim3(DIVUP(Fmax, 256), C, B), dim3(256), 0, s, x, xbs, xpitch, idx, ipitch, nfr,
+                       y, ybs, ypitch);
+}
+
+// ------------------------------------------- depthwise ConvTranspose1d k3 s2 p1 op1 ("pool")
+// out[2q] = w1*v[q] + b ; out[2q+1] = w2*v[q] + w0*v[q+1] + b ; v = leaky(adain(x))
+__global__ void pool_up2_kernel(const float* x, long xbs, int xpitch, const float4* norm, int nstride, float slope,
+                                const float* w, const float* bias, float* y, long ybs, int ypitch, LenSpec ls) {
+    const int b = blockIdx.z, c = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const int L = ls.len(b);
+    if (q >= L) return;
+    const float4 nm = norm[(long)b * nstride + c];
+    const float* xr = x + (long)b * xbs + (long)c * xpitch;
+    float v0 = ((xr[q] - nm.x) * nm.y) * nm.z + nm.w;
+    v0 = v0 < 0.f ? v0 * slope : v0;
+    float v1 = 0.f;
+    if (q + 1 < L) {
+        v1 = ((xr[q + 1] - nm.x) * nm.y) * nm.z + nm.w;
+        v1 = v1 < 0.f ? v1 * slope : v1;
+    }
+    const float w0 = w[c * 3 + 0], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], bb = bias[c];
+    float* yr = y + (long)b * ybs + (long)c * ypitch;
+    yr[2 * q] = w1 * v0 + bb;
+    yr[2 * q + 1] = (w2 * v0 + w0 * v1) + bb;
+}
+void launch_pool_up2(const float* x, long xbs, int xpitch, const float4* norm, int nstride, float slope,
+                     const float* w, const float* bias, float* y, long ybs, int ypitch, LenSpec ls, int C, int B,
+                     int Lmax, hipStream_t s) {
+    hipLaunchKernelGGL(pool_up2_kernel, dim3(DIVUP(Lmax, 256), C, B), dim3(256), 0, s, x, xbs, xpitch, norm, nstride,
+                       slope, w, bias, y, ybs, ypitch, ls);
+}
+
+// Conv1d(1,1,k=3,stride=2,pad=1) of the F0 / N curves: [2F] -> [F]
+__global__ void conv_k3s2_kernel(const float* x, long xbs, const float* w3b, float* y, long ybs, const int* nfr) {
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    const int F = nfr[b];
+    if (f >= F) return;
+    const float* xr = x + (long)b * xbs;
+    const float xm = f > 0 ? xr[2 * f - 1] : 0.f;
+    y[(long)b * ybs + f] = ((w3b[0] * xm + w3b[1] * xr[2 * f]) + w3b[2] * xr[2 * f + 1]) + w3b[3];
+}
+void launch_conv_k3s2(const float* x, long xbs, const float* w3b, float* y, long ybs, const int* nfr, int B, int Fmax,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(conv_k3s2_kernel, dim3(DIVUP(Fmax, 256), B), dim3(256), 0, s, x, xbs, w3b, y, ybs, nfr);
+}
+
+// column 0 of the reflection-padded stage-1 tensor: x[0] = ups[1] + xsrc[0] = (x[2] - xsrc[2]) + xsrc[0]
+__global__ void reflect_fix_kernel(float* y, long ybs, int ypitch, const float* xs, long xbs, int xpitch, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float* yr = y + (long)b * ybs + (long)c * ypitch;
+    const float* sr = xs + (long)b * xbs + (long)c * xpitch;
+    yr[0] = (yr[2] - sr[2]) + sr[0];
+}
+void launch_reflect_fix(float* y, long ybs, int ypitch, const float* xs, long xbs, int xpitch, int C, int B,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(reflect_fix_kernel, dim3(DIVUP(C, 64), B), dim3(64), 0, s, y, ybs, ypitch, xs, xbs, xpitch, C);
+}
+
+// clip(x,-1,1)*32767 -> int16, truncating like numpy's astype('<i2')
+// (basic.tts_kokoro_2_play_pause_works.py:25)
+__global__ void pcm16_kernel(const float* src, int16_t* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = src[i];
+    v = fminf(fmaxf(v, -1.0f), 1.0f) * 32767.0f;
+    dst[i] = (int16_t)v;
+}
+void launch_pcm16(const float* src, int16_t* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)DIVUP(n, 256)), dim3(256), 0, s, src, dst, n);
+}
