@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define K82_HARM 9            // fundamental + 8 overtones (SineGen harmonic_num = 8)
 #define K82_MAXTOK_P1 513   // 512 tokens + 1 (prefix-sum array of the alignment kernel)
 
 struct LenSpec {            // per-sentence valid length
@@ -55,7 +56,7 @@ void launch_style_fc(const float* W, const float* bias, int rows, const float* r
                      float* gb, int gbstride, int B, hipStream_t s);
 // LayerNorm over channels of [B][C][pitch] per (b,t): y = ((x+res)-mean)*rstd*w[c]+bias[c]  (w/bias per channel)
 // or AdaLN: (1+gamma_b[c])*xn + beta_b[c] when gb != nullptr.  Optional LeakyReLU afterwards.
-void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, int pitch, LenSpec ls,
+void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, long ybs, int pitch, LenSpec ls,
                            int C, int B, int Tmax, float eps, const float* w, const float* bias,
                            const float* gb, int gbstride, int goff, float leaky, hipStream_t s);
 void launch_albert_embed(const int64_t* ids, int Tmax, const float* word, const float* pos, const float* type0,
@@ -88,6 +89,7 @@ void launch_conv_k3s2(const float* x, long xbs, const float* w3b, float* y, long
 void launch_copy_rows(const float* x, long xbs, int xpitch, float* y, long ybs, int ypitch, int rows,
                       LenSpec ls, int B, int Lmax, hipStream_t s);
 // harmonic source (source.hip)
+int source_init_constants();   // fills the __constant__ window / twiddle tables of the current device
 void launch_src_phase(const float* f0, long fbs, const int* nfr, int B, float* ph, long pbs, int ppitch, hipStream_t s);
 void launch_src_har(const float* f0, long fbs, const float* ph, long pbs, int ppitch, const int* nfr,
                     const float* noise, const int64_t* noise_off, const uint64_t* seeds,

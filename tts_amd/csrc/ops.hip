@@ -88,7 +88,7 @@ void launch_style_fc(const float* W, const float* bias, int rows, const float* r
 // Thread per (b, t): the C channel values of one position are a strided column, adjacent
 // threads read adjacent t => coalesced.  Two-pass (mean, then centred variance).
 __global__ __launch_bounds__(64) void layernorm_cols_kernel(const float* x, const float* res, float* y, long bs,
-                                                           int pitch, LenSpec ls, int C, float eps, const float* w,
+                                                           long ybs, int pitch, LenSpec ls, int C, float eps, const float* w,
                                                            const float* bias, const float* gb, int gbstride,
                                                            int goff, float leaky) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void layernorm_cols_kernel(const float* x, cons
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(q / C + eps);
-    float* yc = y + (long)b * bs + t;
+    float* yc = y + (long)b * ybs + t;
     const float* g = gb ? gb + (long)b * gbstride + goff : nullptr;
     for (int c = 0; c < C; ++c) {
         float v = (xc[(long)c * pitch] + (rc ? rc[(long)c * pitch] : 0.f) - mean) * rstd;
@@ -114,10 +114,10 @@ __global__ __launch_bounds__(64) void layernorm_cols_kernel(const float* x, cons
         yc[(long)c * pitch] = v;
     }
 }
-void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, int pitch, LenSpec ls, int C,
+void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, long ybs, int pitch, LenSpec ls, int C,
                            int B, int Tmax, float eps, const float* w, const float* bias, const float* gb,
                            int gbstride, int goff, float leaky, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_cols_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, x, res, y, bs, pitch, ls, C,
+    hipLaunchKernelGGL(layernorm_cols_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, x, res, y, bs, ybs, pitch, ls, C,
                        eps, w, bias, gb, gbstride, goff, leaky);
 }
 
