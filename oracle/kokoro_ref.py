@@ -304,11 +304,19 @@ class Generator(nn.Module):
         self.hop = gen_istft_hop_size
         self.conv_post = weight_norm(nn.Conv1d(ch, self.post_n_fft + 2, 7, 1, padding=3))
         # scipy.signal.get_window('hann', n, fftbins=True) == periodic hann
-        self.register_buffer("window", torch.hann_window(gen_istft_n_fft, periodic=True, dtype=torch.float32),
+        n = np.arange(gen_istft_n_fft)
+        self.register_buffer("window", torch.from_numpy((0.5 - 0.5 * np.cos(2.0 * np.pi * n / gen_istft_n_fft)).astype(F32)),
                              persistent=False)
 
     def stft(self, x):
         X = torch.stft(x, self.post_n_fft, self.hop, self.post_n_fft, window=self.window, return_complex=True)
+        # Frame 0 of the reflect-padded signal is exactly symmetric about its centre, so its true
+        # spectrum is real up to the factor (-1)^k: the imaginary part any FFT returns there is pure
+        # rounding noise (~1e-8) whose SIGN decides between angle = +pi and -pi.  Oracle and engine
+        # both replace that noise by its exact value +0 (documented deviation).
+        im = X.imag.clone()
+        im[..., 0] = 0.0
+        X = torch.complex(X.real, im)
         return torch.abs(X), torch.angle(X)
 
     def istft(self, mag, phase):
@@ -436,8 +444,14 @@ class KModelRef(nn.Module):
         return pred_dur, d, duration.reshape(-1)
 
     @torch.no_grad()
-    def forward_with_tokens(self, ids_padded, ref_s, speed=1.0, noise=None, pred_dur=None, taps=None):
-        """Returns (audio f32[600F], pred_dur i64[T]).  ``pred_dur`` may be forced (tests)."""
+    def forward_with_tokens(self, ids_padded, ref_s, speed=1.0, noise=None, pred_dur=None, taps=None,
+                            f0_override=None, n_override=None):
+        """Returns (audio f32[600F], pred_dur i64[T]).  ``pred_dur`` may be forced (tests).
+
+        ``f0_override`` / ``n_override`` (f32[2F]) replace the predicted F0 / N curves before the
+        decoder ("teacher forcing"): the harmonic source integrates F0 into a phase, so an fp32
+        rounding difference of 1e-3 Hz between two implementations grows to ~0.5 rad at the 9th
+        harmonic after 2 s -- stage-wise parity of the decoder needs identical curves."""
         pd, d, _ = self.durations(ids_padded, ref_s, speed, taps)
         if pred_dur is None:
             pred_dur = pd
@@ -451,6 +465,13 @@ class KModelRef(nn.Module):
         s = ref_s[:, 128:]
         en = d.transpose(-1, -2) @ aln
         F0_pred, N_pred, shared = self.predictor.F0Ntrain(en, s)
+        if taps is not None:
+            taps["F0"] = F0_pred
+            taps["N"] = N_pred
+        if f0_override is not None:
+            F0_pred = torch.as_tensor(f0_override, dtype=torch.float32).reshape(1, -1)
+        if n_override is not None:
+            N_pred = torch.as_tensor(n_override, dtype=torch.float32).reshape(1, -1)
         t_en = self.text_encoder(ids_padded)
         asr = t_en @ aln
         if noise is None:
@@ -458,8 +479,6 @@ class KModelRef(nn.Module):
         if taps is not None:
             taps["en"] = en
             taps["shared"] = shared
-            taps["F0"] = F0_pred
-            taps["N"] = N_pred
             taps["t_en"] = t_en
             taps["asr"] = asr
         audio = self.decoder(asr, F0_pred, N_pred, ref_s[:, :128], noise, taps).reshape(-1)

@@ -746,6 +746,7 @@ struct k82_handle {
         else if (noise && noise->seeds) seeds_d = to_device(noise->seeds, (size_t)nb, aF);
         timed(FAM_SRC, 0, [&] { launch_src_phase(f0, P2, nfr_d, nb, ph, (long)K82_HARM * P2, P2, st); });
         timed(FAM_SRC, 0, [&] { launch_src_har(f0, P2, ph, (long)K82_HARM * P2, P2, nfr_d, nz, aoff_d, seeds_d, lin_w, lin_b, hsrc, P600, nb, Fmax, st); });
+        tap("src_ph", ph, K82_HARM, P2, (long)K82_HARM * P2, nb);
         tap("har_source", hsrc, 1, (int)P600, P600, nb);
         float* har = aF.f((size_t)nb * 22 * P120);
         float* harp = aF.f((size_t)nb * 144 * P20);

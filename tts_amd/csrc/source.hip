@@ -6,6 +6,11 @@
 #include "kernels.h"
 #include <math.h>
 
+// HIP implements __fmul_rn/__fadd_rn as plain * and +, which -ffp-contract=fast (the hipcc default)
+// may fuse into an FMA: one rounding fewer = 1 ulp of a 1e4-rad phase.  Contraction is switched
+// off for this whole file (and again on its compile line in the Makefile).
+#pragma clang fp contract(off)
+
 #define DIVUP(a, b) (((a) + (b)-1) / (b))
 
 __constant__ float c_win[20];     // periodic hann, float(0.5 - 0.5 cos(2 pi n / 20))
@@ -118,7 +123,8 @@ void launch_src_har(const float* f0, long fbs, const float* ph, long pbs, int pp
 // Writes har[b][0..10][m] = |X_k|, har[b][11..21][m] = angle(X_k) and the stride-6 polyphase
 // image harp[b][ci*6 + r][q] = har[ci][6q + r - 3] that turns noise_convs[0] (k12, s6, p3) into
 // a 2-tap stride-1 conv for the MFMA kernel.  DC and Nyquist bins have an exactly zero
-// imaginary part (+0, as the r2c FFT returns), so their phase is 0 or +pi.
+// imaginary part (+0, as the r2c FFT returns), so their phase is 0 or +pi; so has frame 0,
+// which is exactly symmetric under reflect padding (its FFT imaginary part is rounding noise).
 __global__ __launch_bounds__(256) void stft_kernel(const float* har_src, long hbs, const int* nfr, float* har, long bs1,
                                                   int p1, float* harp, long bs0, int p0) {
     const int b = blockIdx.y;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* har_src, long hb
             re += v[n] * c_cos[j];
             im -= v[n] * c_sin[j];
         }
-        if (k == 0 || k == 10) im = 0.0f;
+        if (k == 0 || k == 10 || m == 0) im = 0.0f;   // m == 0: exactly symmetric frame, see oracle stft()
         const float mag = sqrtf(re * re + im * im);
         const float ang = atan2f(im, re);
         hb[(long)k * p1] = mag;

@@ -1,0 +1,173 @@
+"""Python face of the C-ABI engine (include/k82.h): one handle = weights on one GPU.
+
+Host arrays are numpy; device buffers may be passed as raw integer pointers (e.g.
+``torch_tensor.data_ptr()``).  No arithmetic happens here -- everything runs in libk82.so, and
+every failure of the library is raised as RuntimeError/ValueError (the reference's callers
+wrap ``create`` in ``try/except Exception`` and fall back: speech7.py:126-133).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, spec, weights as W
+
+
+def _cfg_struct(config):
+    pl = config["plbert"]
+    return _lib.K82Config(
+        n_token=config["n_token"], hidden_dim=config["hidden_dim"], style_dim=config["style_dim"],
+        n_layer=config["n_layer"], max_dur=config["max_dur"], text_kernel=config["text_encoder_kernel_size"],
+        bert_hidden=pl["hidden_size"], bert_heads=pl["num_attention_heads"], bert_inter=pl["intermediate_size"],
+        bert_layers=pl["num_hidden_layers"], bert_max_pos=pl["max_position_embeddings"],
+        bert_embed=spec.ALBERT_EMBED)
+
+
+def _ptr(a):
+    """numpy array / int device pointer / None -> c_void_p."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """Kokoro-82M on one MI355X.  ``state_dicts``: the 5 raw checkpoint state dicts."""
+
+    def __init__(self, state_dicts, config=None, device=0):
+        self.lib = _lib.load()
+        self.config = config or spec.DEFAULT_CONFIG
+        self.device = device
+        self.h = C.c_void_p()
+        cfg = _cfg_struct(self.config)
+        rc = self.lib.k82_create(C.byref(cfg), device, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"k82_create failed ({rc}): {self.lib.k82_last_error(None).decode()}")
+        flat = W.fold_state_dicts(state_dicts, self.config)
+        for name, arr in flat.items():
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * arr.ndim)(*arr.shape)
+            self._check(self.lib.k82_set_tensor(self.h, name.encode(), _ptr(arr), shape, arr.ndim))
+        self._check(self.lib.k82_finalize(self.h))
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.k82_last_error(self.h).decode()
+            if rc in (-22, -28):
+                raise ValueError(f"k82 error {rc}: {msg}")
+            raise RuntimeError(f"k82 error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.k82_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ the hot path
+    @staticmethod
+    def pack(id_lists):
+        """list of per-sentence id lists (WITHOUT pads) -> (ids i64[B,Tmax] with [0,*ids,0], lens i32[B])."""
+        lens = np.array([len(x) + 2 for x in id_lists], dtype=np.int32)
+        tmax = int(lens.max())
+        ids = np.zeros((len(id_lists), tmax), dtype=np.int64)
+        for b, x in enumerate(id_lists):
+            ids[b, 1:1 + len(x)] = np.asarray(x, dtype=np.int64)
+        return ids, lens
+
+    def durations(self, ids, lens, ref_s, speed=None, forced_dur=None, stream=None):
+        """Phase 1.  Returns (pred_dur i32[B,Tmax], n_frames i64[B])."""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        B = lens.shape[0]
+        if isinstance(ids, np.ndarray):
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            tmax = ids.shape[1]
+        else:
+            ids, tmax = ids                      # (device pointer, Tmax)
+        if isinstance(ref_s, np.ndarray):
+            ref_s = np.ascontiguousarray(ref_s, dtype=np.float32).reshape(B, spec.STYLE_DIM_TOTAL)
+        sp = None if speed is None else np.ascontiguousarray(np.broadcast_to(np.asarray(speed, np.float32), (B,)))
+        fd = None if forced_dur is None else np.ascontiguousarray(forced_dur, dtype=np.int32).reshape(B, tmax)
+        pred = np.zeros((B, tmax), dtype=np.int32)
+        nfr = np.zeros((B,), dtype=np.int64)
+        self._check(self.lib.k82_durations(self.h, _ptr(ids), _ptr(lens), B, tmax, _ptr(ref_s), _ptr(sp), _ptr(fd),
+                                           _ptr(pred), _ptr(nfr), _ptr(stream)))
+        self._last_nfr = nfr
+        return pred, nfr
+
+    def decode(self, noise=None, seeds=None, out=None, stream=None):
+        """Phase 2 for the batch of the last ``durations`` call.
+
+        ``out``: None -> host numpy buffer; or (device_ptr, capacity_floats).  Returns
+        (audio, offsets i64[B+1]); audio is the numpy buffer or None when ``out`` was given.
+        """
+        nfr = self._last_nfr
+        total = int(nfr.sum()) * spec.FRAME_SAMPLES
+        nz = K = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float32)
+            assert nz.size == total * 9, (nz.size, total * 9)
+        if seeds is not None:
+            K = np.ascontiguousarray(seeds, dtype=np.uint64)
+        ns = _lib.K82Noise(noise=_ptr(nz), seeds=_ptr(K))
+        off = np.zeros((nfr.shape[0] + 1,), dtype=np.int64)
+        if out is None:
+            audio = np.empty((total,), dtype=np.float32)
+            self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(audio), total, _ptr(off), _ptr(stream)))
+            return audio, off
+        ptr, cap = out
+        self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(ptr), int(cap), _ptr(off), _ptr(stream)))
+        return None, off
+
+    def synthesize(self, id_lists, ref_s, speed=None, noise=None, seeds=None):
+        """list of id lists -> list of f32 audio arrays (+ pred_dur)."""
+        ids, lens = self.pack(id_lists)
+        pred, _ = self.durations(ids, lens, ref_s, speed)
+        audio, off = self.decode(noise=noise, seeds=seeds)
+        return [audio[off[b]:off[b + 1]] for b in range(len(id_lists))], pred
+
+    def pcm16(self, audio):
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        out = np.empty(a.shape, dtype=np.int16)
+        self._check(self.lib.k82_pcm16(self.h, _ptr(a), _ptr(out), a.size, None))
+        return out
+
+    # ------------------------------------------------------------------ hooks
+    def prof_enable(self, on=True):
+        self._check(self.lib.k82_prof_enable(self.h, 1 if on else 0))
+
+    def prof_read(self, name):
+        ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.k82_prof_read(self.h, name.encode(), C.byref(ms), C.byref(n), C.byref(w)))
+        return ms.value, n.value, w.value
+
+    def debug_enable(self, on=True):
+        self._check(self.lib.k82_debug_enable(self.h, 1 if on else 0))
+
+    def debug_get(self, name):
+        """-> f32[B, C, pitch] (padded; slice the valid region yourself)."""
+        dims = (C.c_int64 * 3)()
+        self._check(self.lib.k82_debug_info(self.h, name.encode(), dims))
+        out = np.empty(tuple(int(d) for d in dims), dtype=np.float32)
+        self._check(self.lib.k82_debug_copy(self.h, name.encode(), _ptr(out)))
+        return out
+
+    def op_conv1d(self, x, w, bias=None, dil=1, act=0, slope=1.0, alpha=None, iters=1):
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        B, cin, L = x.shape
+        cout, _, taps = w.shape
+        y = np.empty((B, cout, L), np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        a = None if alpha is None else np.ascontiguousarray(alpha, np.float32)
+        ms = C.c_float()
+        self._check(self.lib.k82_op_conv1d(self.h, _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, cin, cout, L, taps, dil,
+                                           act, slope, _ptr(a), iters, C.byref(ms)))
+        return y, ms.value
