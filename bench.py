@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Kokoro-82M audio-seconds synthesized per wall-second on N MI355X.
+
+Workload at every N (weak scaling): BASELINE.json configs[1] per GPU -- fp32, a synthetic batch
+of 64 phoneme sequences x 256 tokens (254 random ids + the two pad tokens), seeded synthetic
+weights of the exact Kokoro-82M architecture (no checkpoint exists offline), style rows of a
+synthetic voice pack, speed 1.0.  A step = the whole hot path for one batch: k82_durations
+(ALBERT .. duration head) + k82_decode (length regulation .. iSTFT), durations PREDICTED by the
+model (no forced durations), inputs already resident in HBM, audio left in HBM.
+
+One process per GPU (torch.distributed over RCCL only for the barrier and the max/sum of two
+scalars -- sentences are independent, there is no data-path collective).  Rank 0 prints ONE
+JSON line.  `roofline` is for the dominant kernel conv_mfma_kernel<2,2> (fp32 MFMA), timed with
+HIP events on the engine's stream during the timed steps; `cpu_baseline` is the CPU oracle
+(a stand-in "port": the reference's onnxruntime path is not installable offline) on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--tokens", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from tts_amd import spec
+    from tts_amd.engine import Engine
+
+    sds = spec.synthetic_state_dicts(0)
+    eng = Engine(sds, device=local)
+    B, T = args.batch, args.tokens
+    rng = np.random.default_rng(1000 + rank)                 # each rank synthesizes different sentences
+    ids = np.zeros((B, T), dtype=np.int64)
+    ids[:, 1:T - 1] = rng.integers(1, 178, size=(B, T - 2))
+    lens = np.full((B,), T, dtype=np.int32)
+    pack = spec.synthetic_voice_pack(1)
+    ref_s = np.repeat(pack[T - 3], B, axis=0).astype(np.float32)   # KPipeline row: pack[len(phonemes) - 1]
+    seeds = np.arange(B, dtype=np.uint64) + np.uint64(rank * 100000)
+    ids_d = torch.from_numpy(ids).cuda()
+    ref_d = torch.from_numpy(ref_s).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # sizing pass (also the first warm-up): durations are deterministic for fixed inputs
+    _, nfr = eng.durations((ids_d.data_ptr(), T), lens, ref_d.data_ptr(), stream=stream)
+    total = int(nfr.sum()) * spec.FRAME_SAMPLES
+    audio_d = torch.empty(total, dtype=torch.float32, device="cuda")
+
+    def step():
+        eng.durations((ids_d.data_ptr(), T), lens, ref_d.data_ptr(), stream=stream)
+        eng.decode(seeds=seeds, out=(audio_d.data_ptr(), total), stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_n, conv_flops = eng.prof_read("conv_mfma_2x2")
+    fam = {}
+    for name in ("conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "source", "other"):
+        ms, n, w = eng.prof_read(name)
+        fam[name] = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps}
+    eng.prof_enable(False)
+
+    audio_s = total / spec.SAMPLE_RATE
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        a = torch.tensor([audio_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        dt, audio_all = float(t.item()), float(a.item())
+    else:
+        audio_all = audio_s
+    finite = bool(torch.isfinite(audio_d).all().item())
+
+    if rank == 0:
+        out = {
+            "metric": "audio-sec synthesized/sec (node) Kokoro-82M",
+            "value": audio_all * args.steps / dt,
+            "unit": "audio-s/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic phoneme ids, seeded random weights of the Kokoro-82M architecture, synthetic voice pack",
+            "config": {"workload": "configs[1]: Kokoro-82M fp32, 64 phoneme sequences x 256 tokens per GPU, "
+                                   "durations predicted by the model", "batch_per_gpu": B, "tokens": T,
+                       "frames_per_gpu": int(nfr.sum()), "audio_s_per_step_per_gpu": audio_s,
+                       "parallelism": f"dp{world} (sentence sharding, no data-path collective)",
+                       "audio_finite": finite},
+            "roofline": {
+                "kernel": "conv_mfma_kernel<2,2> (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma",
+                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "traffic": None,
+                "launches_per_step": conv_n / args.steps,
+                "avg_launch_ms": conv_ms / conv_n if conv_n else None,
+                "ms_per_step": conv_ms / args.steps,
+                "algorithmic_flops_per_step": conv_flops / args.steps,
+            },
+            "other_kernels": fam,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sds, ids, ref_s, T)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sds, ids, ref_s, T, budget_s=20.0):
+    """The CPU oracle on the first sentences of the same batch, B=1 sequentially (how the
+    reference runs), for ~budget_s seconds of CPU work."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    import torch
+    from tts_amd import spec
+    from oracle import kokoro_ref as R
+    model = R.build(spec.DEFAULT_CONFIG, sds)
+    threads = torch.get_num_threads()
+    done_audio, n = 0.0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < ids.shape[0]:
+        x = torch.from_numpy(ids[n:n + 1, :T].copy())
+        a, _ = model.forward_with_tokens(x, torch.from_numpy(ref_s[n:n + 1].copy()), 1.0)
+        done_audio += a.numel() / spec.SAMPLE_RATE
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": done_audio / dt, "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} of the 64 sentences (256 tokens each), batch=1 sequential, "
+                      f"fp32 torch-CPU restatement (oracle/kokoro_ref.py), {dt:.1f} s of CPU work"}
+
+
+if __name__ == "__main__":
+    main()

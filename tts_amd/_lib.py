@@ -39,6 +39,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C tts_amd/csrc` (or __graft_entry__.build()). "
             "tts_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HIP runtimes in
+    # one process cannot both own the GPU ("no ROCm-capable device is detected"), so torch is
+    # imported FIRST: libk82.so's DT_NEEDED libamdhip64.so.7 then binds to the copy already loaded.
+    # Without torch (a plain C consumer) the system runtime under /opt/rocm/lib is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
     lib.k82_create.argtypes = [C.POINTER(K82Config), i32, C.POINTER(vp)]
