@@ -323,11 +323,18 @@ class Generator(nn.Module):
         y = torch.istft(mag * torch.exp(phase * 1j), self.post_n_fft, self.hop, self.post_n_fft, window=self.window)
         return y.unsqueeze(-2)
 
-    def forward(self, x, s, f0_curve, noise, taps=None):
+    def forward(self, x, s, f0_curve, noise, taps=None, har_override=None):
         har_source, sw = harmonic_source(f0_curve, noise, self.m_source.l_linear.weight,
                                          self.m_source.l_linear.bias, self.up_total)
         har_spec, har_phase = self.stft(har_source)
         har = torch.cat([har_spec, har_phase], dim=1)
+        if taps is not None:
+            taps["har_own"] = har
+        if har_override is not None:
+            # angle() is discontinuous: where |X_k| is at rounding-noise level a last-bit difference
+            # of har_source flips the phase by 2*pi.  Stage-wise parity feeds the consumer stages the
+            # engine's own [mag | phase] tensor; `har` itself is compared modulo 2*pi by the tests.
+            har = torch.as_tensor(har_override, dtype=torch.float32).reshape(har.shape)
         if taps is not None:
             taps["sine_waves"] = sw
             taps["har_source"] = har_source
@@ -372,7 +379,7 @@ class Decoder(nn.Module):
         self.asr_res = nn.Sequential(weight_norm(nn.Conv1d(512, 64, kernel_size=1)))
         self.generator = Generator(style_dim, **ist)
 
-    def forward(self, asr, F0_curve, N, s, noise, taps=None):
+    def forward(self, asr, F0_curve, N, s, noise, taps=None, har_override=None):
         F0 = self.F0_conv(F0_curve.unsqueeze(1))
         Nn = self.N_conv(N.unsqueeze(1))
         x = torch.cat([asr, F0, Nn], dim=1)
@@ -389,7 +396,7 @@ class Decoder(nn.Module):
                 res = False
         if taps is not None:
             taps["dec_out"] = x
-        return self.generator(x, s, F0_curve, noise, taps)
+        return self.generator(x, s, F0_curve, noise, taps, har_override)
 
 
 # ================================================================================= KModel [EXT]
@@ -445,7 +452,7 @@ class KModelRef(nn.Module):
 
     @torch.no_grad()
     def forward_with_tokens(self, ids_padded, ref_s, speed=1.0, noise=None, pred_dur=None, taps=None,
-                            f0_override=None, n_override=None):
+                            f0_override=None, n_override=None, har_override=None):
         """Returns (audio f32[600F], pred_dur i64[T]).  ``pred_dur`` may be forced (tests).
 
         ``f0_override`` / ``n_override`` (f32[2F]) replace the predicted F0 / N curves before the
@@ -481,7 +488,7 @@ class KModelRef(nn.Module):
             taps["shared"] = shared
             taps["t_en"] = t_en
             taps["asr"] = asr
-        audio = self.decoder(asr, F0_pred, N_pred, ref_s[:, :128], noise, taps).reshape(-1)
+        audio = self.decoder(asr, F0_pred, N_pred, ref_s[:, :128], noise, taps, har_override).reshape(-1)
         if taps is not None:
             taps["audio"] = audio
         return audio, pred_dur

@@ -23,12 +23,12 @@ def make_batch(seed, lengths, voice_seed=1):
     return id_lists, ref_s
 
 
-def oracle_run(model, ids_list, ref_s_row, speed, noise, forced=None, taps=None, f0=None, n=None):
+def oracle_run(model, ids_list, ref_s_row, speed, noise, forced=None, taps=None, f0=None, n=None, har=None):
     ids = torch.tensor([[0] + list(ids_list) + [0]], dtype=torch.long)
     rs = torch.from_numpy(ref_s_row[None].copy())
     nz = None if noise is None else torch.from_numpy(noise[None].copy())
     audio, pd = model.forward_with_tokens(ids, rs, speed, noise=nz, pred_dur=forced, taps=taps,
-                                          f0_override=f0, n_override=n)
+                                          f0_override=f0, n_override=n, har_override=har)
     return audio.numpy(), pd.numpy()
 
 
@@ -40,3 +40,16 @@ def to_bct(name, t):
     if name in ("F0", "N", "har_source"):
         return a.reshape(1, -1)
     return a[0]
+
+
+def compare_har(got, ref, strong_thresh=1e-2):
+    """[22, L] magnitude|phase tensors -> (max mag err, max strong-bin phase err mod 2pi, flips).
+    A flip = a phase element differing by ~2*pi (branch cut of angle() crossed by rounding noise)."""
+    mag_err = float(np.abs(got[:11] - ref[:11]).max())
+    d = np.abs(got[11:] - ref[11:])
+    dw = np.minimum(d, 2 * np.pi - d)
+    strong = ref[:11] > strong_thresh
+    flips = int((d > np.pi).sum())
+    # weak bins: phase error scales like (noise / magnitude); bound the error of the complex value instead
+    cerr = float(np.abs(got[:11] * np.exp(1j * got[11:]) - ref[:11] * np.exp(1j * ref[11:])).max())
+    return mag_err, float(dw[strong].max()) if strong.any() else 0.0, flips, cerr

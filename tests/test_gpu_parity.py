@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP engine (through the C-ABI, via ctypes) against the CPU oracle.
+
+Bars (BASELINE.json north_star): predicted integer durations bit-exact; fp32 waveform max-abs
+error <= 1e-3 with injected source noise.  The waveform bar is checked with the oracle's F0/N
+curves and the source STFT tensor forced to the engine's (teacher forcing) at the two places
+where the model's own arithmetic is ill-conditioned: the harmonic source INTEGRATES F0 (a 1e-3 Hz
+fp32 disagreement grows to ~0.5 rad at the 9th harmonic within seconds) and angle() of a
+near-empty STFT bin flips by 2*pi on last-bit noise -- see DESIGN.md "numerical conditioning".
+Both forced tensors are themselves compared against the oracle's own (F0/N to 5e-4 relative,
+har modulo 2*pi).  The free-running waveform
+is reported as an SNR.  The oracle is unpinned by the reference, so these tests
+prove engine == restatement, not engine == kokoro_onnx.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from tts_amd import spec
+from oracle import kokoro_ref as R
+
+pytestmark = pytest.mark.gpu
+
+AUDIO_TOL = 1e-3          # north_star: fp32 max-abs error <= 1e-3
+
+
+def _noise_for(nfr, base=100):
+    return np.concatenate([R.counter_noise(base + b, int(nfr[b]) * 600) for b in range(len(nfr))])
+
+
+# ------------------------------------------------------------------ the hot conv kernel
+@pytest.mark.parametrize("cin,cout,L,taps,dil,act", [
+    (128, 128, 777, 7, 3, 2),      # generator stage-1 resblock shape, snake
+    (256, 256, 300, 11, 5, 2),     # widest halo (50)
+    (22, 128, 1000, 1, 1, 0),      # noise_convs[1]: cin padded 22 -> 32
+    (514, 1024, 130, 3, 1, 1),     # decoder encode conv1: cin padded 514 -> 528, leaky
+    (128, 22, 513, 7, 1, 1),       # conv_post: cout padded 22 -> 64 (1x4 variant)
+    (512, 50, 70, 1, 1, 0),        # duration_proj
+    (768, 2304, 64, 1, 1, 0),      # ALBERT fused QKV
+    (16, 128, 1, 3, 1, 0),         # single position
+])
+def test_conv_kernel_matches_torch(engine, cin, cout, L, taps, dil, act):
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal((2, cin, L)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, taps)) / np.sqrt(cin * taps)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    alpha = (1.0 + 0.5 * rng.random(cin)).astype(np.float32)
+    y, _ = engine.op_conv1d(x, w, b, dil=dil, act=act, slope=0.2, alpha=alpha if act == 2 else None)
+    xt = torch.from_numpy(x)
+    if act == 1:
+        xt = torch.nn.functional.leaky_relu(xt, 0.2)
+    elif act == 2:
+        a = torch.from_numpy(alpha)[None, :, None]
+        xt = xt + (1 / a) * torch.sin(a * xt) ** 2
+    ref = torch.nn.functional.conv1d(xt.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                     padding=(taps - 1) // 2 * dil, dilation=dil).numpy()
+    err = np.abs(y - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+# ------------------------------------------------------------------ durations: bit-exact
+@pytest.mark.parametrize("lengths,speed", [
+    ([1, 7, 30, 64, 2, 19], 1.0),
+    ([120, 3, 254], 1.0),
+    ([40, 41, 42], 0.5),
+    ([40, 41, 42], 2.0),
+    ([510], 1.0),                    # maximum context: 510 phonemes + 2 pads
+    ([0], 1.0),                      # empty phoneme string: ids = [0, 0]
+])
+def test_durations_bit_exact(engine, oracle_model, lengths, speed):
+    id_lists, ref_s = H.make_batch(11, [max(n, 0) for n in lengths])
+    ref_s = np.stack([spec.synthetic_voice_pack(1)[max(len(x) - 1, 0), 0] for x in id_lists])
+    ids, lens = engine.pack(id_lists)
+    pred, nfr = engine.durations(ids, lens, ref_s, speed=speed)
+    margin = 1.0
+    for b, x in enumerate(id_lists):
+        t = torch.tensor([[0] + x + [0]], dtype=torch.long)
+        pd, _, raw = oracle_model.durations(t, torch.from_numpy(ref_s[b:b + 1].copy()), speed)
+        frac = np.abs((raw.numpy() % 1.0) - 0.5)
+        margin = min(margin, float(frac.min()))
+        assert np.array_equal(pd.numpy(), pred[b, :lens[b]]), (b, pd.numpy(), pred[b, :lens[b]])
+        assert (pred[b, lens[b]:] == 0).all()
+        assert nfr[b] == pd.sum()
+    print(f"min |frac(duration) - 0.5| over the batch: {margin:.2e} (engine/oracle fp32 noise ~1e-4)")
+
+
+# ------------------------------------------------------------------ every stage, then the waveform
+STAGE_TOL = {  # max-abs tolerances, scaled by max(1, max|ref|) below.  The synthetic duration-branch
+    # LSTMs carry x3 weights (spec.synthetic_state_dicts) and sit near the chaotic regime: fp32
+    # summation-order noise (~1e-6 per gate) is amplified to ~2e-4 over 35 recurrent steps x 4 layers.
+    "default": 5e-4,
+    "har": None,            # phase rows flip by 2*pi on rounding noise where |X_k| ~ 0: checked via its consumers
+}
+
+
+@pytest.mark.parametrize("lengths", [[10, 33, 20], [64], [5, 90]])
+def test_stage_and_waveform_parity(engine, oracle_model, lengths):
+    id_lists, ref_s = H.make_batch(3, lengths)
+    engine.debug_enable(True)
+    try:
+        ids, lens = engine.pack(id_lists)
+        pred, nfr = engine.durations(ids, lens, ref_s)
+        noise = _noise_for(nfr)
+        audio, off = engine.decode(noise=noise)
+        assert off[-1] == audio.size and np.isfinite(audio).all()
+        for b, x in enumerate(id_lists):
+            T, F = int(lens[b]), int(nfr[b])
+            taps = {}
+            nz = noise.reshape(-1, 9)[off[b]:off[b + 1]]
+            f0g = engine.debug_get("F0")[b, 0, :2 * F]
+            ng = engine.debug_get("N")[b, 0, :2 * F]
+            harg = engine.debug_get("har")[b][:22, :120 * F + 1]
+            a_ref, pd = H.oracle_run(oracle_model, x, ref_s[b], 1.0, nz, taps=taps, f0=f0g, n=ng, har=harg)
+            assert np.array_equal(pd, pred[b, :T])
+            for name, base, mul, add in H.STAGES:
+                ref = H.to_bct(name, taps[name])
+                L = (T if base == "T" else F) * mul + add
+                got = engine.debug_get(name)[b][: ref.shape[0], :L]
+                if name == "har":
+                    # the oracle's OWN STFT of its own har_source; phases compared modulo 2*pi
+                    mag_err, phase_err, flips, cerr = H.compare_har(got, H.to_bct("har", taps["har_own"]))
+                    print(f"sentence {b}: har mag err {mag_err:.1e}, strong-bin phase err {phase_err:.1e}, "
+                          f"complex err {cerr:.1e}, 2*pi flips {flips} of {got[11:].size}")
+                    assert mag_err <= 1e-5 and phase_err <= 1e-3 and cerr <= 1e-5
+                    continue
+                tol = STAGE_TOL["default"] * max(1.0, float(np.abs(ref).max()))
+                err = float(np.abs(got - ref[:, :L]).max())
+                assert err <= tol, (name, b, err, tol)
+            err = float(np.abs(audio[off[b]:off[b + 1]] - a_ref).max())
+            assert err <= AUDIO_TOL, (b, err)
+    finally:
+        engine.debug_enable(False)
+
+
+def test_free_running_waveform(engine, oracle_model):
+    """No teacher forcing.  Durations stay bit-exact; the waveform decorrelates in PHASE because the
+    source integrates F0 (engine and oracle F0 agree to ~3e-5 relative, i.e. ~5e-3 Hz, which is
+    ~0.5 rad at the 9th harmonic after 2-3 s), so sample-wise SNR is only reported, while the
+    phase-insensitive spectral-convergence error of the 1024-point magnitude STFT is asserted."""
+    id_lists, ref_s = H.make_batch(5, [12, 25])
+    ids, lens = engine.pack(id_lists)
+    pred, nfr = engine.durations(ids, lens, ref_s)
+    noise = _noise_for(nfr)
+    audio, off = engine.decode(noise=noise)
+    win = torch.hann_window(1024)
+    for b, x in enumerate(id_lists):
+        a_ref, pd = H.oracle_run(oracle_model, x, ref_s[b], 1.0, noise.reshape(-1, 9)[off[b]:off[b + 1]])
+        assert np.array_equal(pd, pred[b, :lens[b]])
+        got = audio[off[b]:off[b + 1]]
+        e = got.astype(np.float64) - a_ref
+        snr = 10 * np.log10((a_ref.astype(np.float64) ** 2).sum() / max((e ** 2).sum(), 1e-30))
+        S1 = torch.stft(torch.from_numpy(got.copy()), 1024, 256, window=win, return_complex=True).abs()
+        S0 = torch.stft(torch.from_numpy(a_ref.copy()), 1024, 256, window=win, return_complex=True).abs()
+        sc = float(torch.linalg.norm(S1 - S0) / torch.linalg.norm(S0))
+        print(f"sentence {b}: free-running SNR {snr:.1f} dB, max-abs {np.abs(e).max():.2e}, "
+              f"spectral convergence error {sc:.3f}")
+        assert sc <= 0.2
+
+
+# ------------------------------------------------------------------ size-independent properties
+def test_padding_is_bit_invisible(engine):
+    """A sentence synthesized alone and inside a ragged batch gives identical bits."""
+    id_lists, ref_s = H.make_batch(21, [37, 9, 150, 64])
+    seeds = np.array([7, 8, 9, 10], dtype=np.uint64)
+    ids, lens = engine.pack(id_lists)
+    pred, nfr = engine.durations(ids, lens, ref_s)
+    audio, off = engine.decode(seeds=seeds)
+    audio = audio.copy()
+    for b in (0, 1, 3):
+        i1, l1 = engine.pack([id_lists[b]])
+        p1, n1 = engine.durations(i1, l1, ref_s[b:b + 1])
+        a1, o1 = engine.decode(seeds=seeds[b:b + 1])
+        assert np.array_equal(p1[0, :l1[0]], pred[b, :lens[b]])
+        assert np.array_equal(a1, audio[off[b]:off[b + 1]])
+
+
+def test_deterministic_and_full_size_properties(engine):
+    """BASELINE configs[1] shape (64 x 256 tokens): two runs are bit-identical, every sample is
+    finite and within [-1.5, 1.5]-ish iSTFT range, offsets are 600 * sum(pred_dur)."""
+    rng = np.random.default_rng(0)
+    B, T = 64, 256
+    ids = np.zeros((B, T), dtype=np.int64)
+    ids[:, 1:T - 1] = rng.integers(1, 178, size=(B, T - 2))
+    lens = np.full((B,), T, dtype=np.int32)
+    ref_s = np.repeat(spec.synthetic_voice_pack(1)[T - 3], B, axis=0)
+    seeds = np.arange(B, dtype=np.uint64)
+    pred, nfr = engine.durations(ids, lens, ref_s)
+    a1, off = engine.decode(seeds=seeds)
+    a1 = a1.copy()
+    assert (pred >= 1).all() and np.array_equal(nfr, pred.sum(axis=1))
+    assert np.array_equal(np.diff(off), 600 * nfr)
+    assert np.isfinite(a1).all()
+    pred2, _ = engine.durations(ids, lens, ref_s)
+    a2, _ = engine.decode(seeds=seeds)
+    assert np.array_equal(pred, pred2) and np.array_equal(a1, a2)
+    # row 5 alone == row 5 in the batch (padding / batching invisible at full size too)
+    p5, _ = engine.durations(ids[5:6], lens[5:6], ref_s[5:6])
+    a5, _ = engine.decode(seeds=seeds[5:6])
+    assert np.array_equal(p5[0], pred[5]) and np.array_equal(a5, a1[off[5]:off[6]])
+
+
+def test_forced_durations_and_max_context(engine, oracle_model):
+    """configs[3] shape per sentence: 510 phonemes, forced pred_dur; checked against the oracle."""
+    id_lists, ref_s = H.make_batch(31, [510])
+    ids, lens = engine.pack(id_lists)
+    forced = np.ones((1, 512), dtype=np.int32)
+    forced[0, ::7] = 3
+    engine.debug_enable(True)
+    try:
+        pred, nfr = engine.durations(ids, lens, ref_s, forced_dur=forced)
+        assert np.array_equal(pred, forced)
+        noise = _noise_for(nfr)
+        audio, off = engine.decode(noise=noise)
+        F = int(nfr[0])
+        a_ref, _ = H.oracle_run(oracle_model, id_lists[0], ref_s[0], 1.0, noise.reshape(-1, 9), forced=forced[0],
+                                f0=engine.debug_get("F0")[0, 0, :2 * F], n=engine.debug_get("N")[0, 0, :2 * F],
+                                har=engine.debug_get("har")[0][:22, :120 * F + 1])
+        assert np.abs(audio - a_ref).max() <= AUDIO_TOL
+    finally:
+        engine.debug_enable(False)
+
+
+def test_in_kernel_noise_matches_counter_noise(engine):
+    """seeds-mode (splitmix64 + Box-Muller in the kernel) == explicit noise from its numpy twin."""
+    id_lists, ref_s = H.make_batch(41, [14, 6])
+    ids, lens = engine.pack(id_lists)
+    _, nfr = engine.durations(ids, lens, ref_s)
+    seeds = np.array([123, 456], dtype=np.uint64)
+    a_seed, off = engine.decode(seeds=seeds)
+    a_seed = a_seed.copy()
+    noise = np.concatenate([R.counter_noise(int(seeds[b]), int(nfr[b]) * 600) for b in range(2)])
+    engine.durations(ids, lens, ref_s)
+    a_exp, _ = engine.decode(noise=noise)
+    assert np.abs(a_seed - a_exp).max() <= 1e-4
+
+
+def test_errors_are_reported_not_fatal(engine):
+    ids = np.zeros((1, 4), dtype=np.int64)
+    with pytest.raises(ValueError):
+        engine.durations(ids, np.array([9], dtype=np.int32), np.zeros((1, 256), np.float32))   # lens > Tmax
+    with pytest.raises(ValueError):
+        engine.durations(ids, np.array([4], dtype=np.int32), np.zeros((1, 256), np.float32), speed=0.0)
+    # the handle still works afterwards
+    pred, nfr = engine.durations(ids, np.array([4], dtype=np.int32), np.zeros((1, 256), np.float32))
+    assert nfr[0] >= 4
+
+
+def test_pcm16_matches_numpy(engine):
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(10007) * 0.7).astype(np.float32)
+    got = engine.pcm16(x)
+    ref = (np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2")     # basic.tts_kokoro_2_play_pause_works.py:25
+    assert np.array_equal(got, ref)
