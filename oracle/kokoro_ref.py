@@ -21,9 +21,10 @@ Differences from the hexgrad module, all deliberate and documented:
     phase of SineGen provably never reaches the output (it is added to sample 0 only and the
     1/300 linear down-interpolation reads samples 300i+149 and 300i+150) -- asserted by
     tests/test_oracle_kat.py::test_sinegen_matches_literal_torch.
-  * The phase path (cumsum / linear interpolation) is written out in explicit fp32 steps with
-    no fused multiply-add, because sin() is applied to phases of 1e5..1e6 rad where one fp32
-    ulp is ~0.01-0.06 rad: the GPU mirrors these steps bit for bit.
+  * The phase path (cumsum / linear interpolation) is written out in explicit fp32 steps,
+    including the two places where torch's CPU kernel fuses a multiply-add, because sin() is
+    applied to phases of 1e4..1e6 rad where one fp32 ulp is ~0.001-0.06 rad: the GPU mirrors these
+    steps bit for bit, and a KAT proves them bit-identical to the literal torch ops.
   * Batched inputs are run sentence by sentence (the reference runs batch = 1).
 """
 from __future__ import annotations
@@ -248,15 +249,23 @@ def sinegen_phase(f0_lo: np.ndarray, upsample: int = 300, sr: float = 24000.0, h
     L = n * upsample
     j = np.arange(L, dtype=F32)
     scale = F32(1.0 / upsample)
-    src = ((scale * (j + F32(0.5)).astype(F32)).astype(F32) - F32(0.5)).astype(F32)
+    # torch's CPU upsample_linear1d (AVX2/AVX512 builds, FMA contraction on) evaluates
+    #   src = fma(scale, j + 0.5, -0.5) ;  out = fma(1 - lam, p[i0], lam * p[i1])
+    # -- established bit for bit by tests/test_cpu_oracle_kat.py::test_sinegen_matches_literal_torch.
+    src = _fma32(np.full(L, scale, F32), (j + F32(0.5)).astype(F32), np.full(L, F32(-0.5), F32))
     src = np.maximum(src, F32(0.0))
     i0 = np.floor(src).astype(np.int64)
     lam = (src - i0.astype(F32)).astype(F32)
     i1 = np.minimum(i0 + 1, n - 1)
     w0 = (F32(1.0) - lam).astype(F32)
-    a = (w0[:, None] * ph[i0]).astype(F32)
     b = (lam[:, None] * ph[i1]).astype(F32)
-    return (a + b).astype(F32)
+    return _fma32(np.broadcast_to(w0[:, None], b.shape), ph[i0], b)
+
+
+def _fma32(a, b, c):
+    """fp32 fused multiply-add emulated through fp64 (the product of two fp32 is exact in fp64; the
+    double rounding of the sum differs from a true FMA with probability ~2^-29 per element)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F32)
 
 
 def harmonic_source(f0_curve: torch.Tensor, noise: torch.Tensor, lin_w: torch.Tensor, lin_b: torch.Tensor,

@@ -1,0 +1,180 @@
+"""Host logic: splitters, tokenizer/chunking, trim, weight/voice loaders, scheduler, ordered gather
+across 2 ranks (gloo, CPU)."""
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+warnings.filterwarnings("ignore")
+
+from tts_amd import scheduler as S, spec, text as T, weights as W  # noqa: E402
+
+TEXT = ("This is the 1st sentence. This is 2nd sentence. This is 3rd sentence! Is this 4th sentence? "
+        "This is 5th sentence.")       # basic.tts_kokoro.py:12
+
+
+def test_splitters_follow_the_reference_callers():
+    assert T.split_sentences_basic(TEXT) == ["This is the 1st sentence.", "This is 2nd sentence.",
+                                             "This is 3rd sentence!", "Is this 4th sentence?", "This is 5th sentence."]
+    assert T.split_sentences_speech7(TEXT) == T.split_sentences_basic(TEXT)
+    assert T.split_sentences_speech7("No punctuation at the end") == ["No punctuation at the end"]
+    assert T.split_sentences_speech7("Wait... what?!  Yes.") == ["Wait...", "what?!", "Yes."]
+    assert T.split_sentences_newline("One.\nTwo\n\nThree. Four.") == ["One.", "Two", "Three.", "Four."]
+    assert T.split_sentences_abbrev("Dr. Smith met Mr. Jones at 5 p.m. They talked. e.g. this stays.") == [
+        "Dr. Smith met Mr. Jones at 5 p.m.", "They talked. e.g. this stays."]
+    assert T.split_sentences_abbrev("") == [] and T.split_sentences_speech7("") == []
+
+
+def test_tokenize_and_chunking():
+    ids = T.tokenize("hɛlˈoʊ wɜːld!")
+    assert ids == [spec.DEFAULT_VOCAB[c] for c in "hɛlˈoʊ wɜːld!"]
+    assert T.tokenize("h☃i") == [spec.DEFAULT_VOCAB["h"], spec.DEFAULT_VOCAB["i"]]     # unknown dropped
+    assert len(set(spec.DEFAULT_VOCAB.values())) == len(spec.DEFAULT_VOCAB) and max(spec.DEFAULT_VOCAB.values()) < 178
+    long = ", ".join(["abcdefghij" * 5] * 30)                                       # ~1500 phonemes
+    chunks = T.split_phonemes(long)
+    assert len(chunks) >= 3 and all(0 < len(c) < 510 for c in chunks)
+    assert "".join(chunks).replace(" ", "").replace(",", "") == long.replace(" ", "").replace(",", "")
+    assert T.split_phonemes("short one.") == ["short one."]
+    assert T.split_phonemes("") == []
+    assert all(len(c) < 510 for c in T.split_phonemes("a" * 1300))
+
+
+def test_style_row_conventions():
+    pack = spec.synthetic_voice_pack(1)
+    assert np.array_equal(T.style_row(pack, 12, "kokoro_onnx"), pack[12, 0])
+    assert np.array_equal(T.style_row(pack, 12, "kpipeline"), pack[11, 0])
+    assert np.array_equal(T.style_row(pack, 0, "kpipeline"), pack[0, 0])
+
+
+def test_trim_audio():
+    y = np.zeros(24000, np.float32)
+    y[6000:12000] = 0.5 * np.sin(np.arange(6000) * 0.1)
+    t, (s, e) = T.trim_audio(y)
+    assert 0 < s <= 6000 and 12000 <= e < 24000 and s % 512 == 0 and e % 512 == 0
+    assert (s, e) == (5120, 13312)      # frames 10..25 of 2048 samples, hop 512, overlap the burst
+    assert np.array_equal(t, y[s:e])
+    assert T.trim_audio(np.zeros(100, np.float32))[0].size == 0
+
+
+def test_surrogate_g2p_is_flagged():
+    ps, backend = T.phonemize("Hello, World! It's 5 o'clock.", "en-us")
+    assert backend in ("misaki", "phonemizer", "surrogate")
+    if backend == "surrogate":
+        assert ps == "hello, world! its okloks." or all(c in spec.DEFAULT_VOCAB for c in ps)
+
+
+# ------------------------------------------------------------------ loaders
+def test_pth_roundtrip_and_shape_assertions(tmp_path, synthetic_sds):
+    p = tmp_path / "kokoro-v1_0.pth"
+    torch.save({k: {n: torch.from_numpy(v) for n, v in sd.items()} for k, sd in synthetic_sds.items()}, p)
+    sds = W.load_pth(str(p))
+    flat = W.fold_state_dicts(sds)
+    assert len(flat) == 459 and all(v.dtype == np.float32 for v in flat.values())
+    assert flat["decoder.generator.ups.0.weight"].shape == (512, 256, 20)
+    assert flat["predictor.F0.1.pool.weight"].shape == (512, 1, 3)
+    assert "bert.pooler.weight" in flat and not any(k.endswith(("weight_g", "weight_v")) for k in flat)
+    bad = {k: dict(v) for k, v in sds.items()}
+    del bad["decoder"]["module.generator.conv_post.bias"]
+    with pytest.raises(KeyError, match="conv_post.bias"):
+        W.fold_state_dicts(bad)
+    bad = {k: dict(v) for k, v in sds.items()}
+    bad["bert_encoder"]["module.weight"] = torch.zeros(512, 700)
+    with pytest.raises(ValueError, match="bert_encoder.weight"):
+        W.fold_state_dicts(bad)
+    # new-style parametrization keys are accepted too
+    alt = {k: dict(v) for k, v in sds.items()}
+    te = alt["text_encoder"]
+    te["module.cnn.0.0.parametrizations.weight.original0"] = te.pop("module.cnn.0.0.weight_g")
+    te["module.cnn.0.0.parametrizations.weight.original1"] = te.pop("module.cnn.0.0.weight_v")
+    assert np.array_equal(W.fold_state_dicts(alt)["text_encoder.cnn.0.0.weight"], flat["text_encoder.cnn.0.0.weight"])
+
+
+def test_voice_loaders_and_search_order(tmp_path, monkeypatch):
+    packs = {"af_sarah": spec.synthetic_voice_pack(3), "af_heart": spec.synthetic_voice_pack(4)}
+    npz = tmp_path / "voices-v1.0.bin"
+    with open(npz, "wb") as f:
+        np.savez(f, **packs)
+    v = W.load_voices(str(npz))
+    assert sorted(v) == ["af_heart", "af_sarah"] and v["af_sarah"].shape == (510, 1, 256)
+    assert np.array_equal(v["af_sarah"], packs["af_sarah"])
+    d = tmp_path / "voices"
+    d.mkdir()
+    torch.save(torch.from_numpy(packs["af_heart"]), d / "af_heart.pt")
+    assert np.array_equal(W.load_voices(str(d))["af_heart"], packs["af_heart"])
+    (tmp_path / "kokoro-v1_0.pth").write_bytes(b"x")
+    (tmp_path / "config.json").write_text("{}")
+    monkeypatch.setenv("KOKORO_ONNX_PATH", str(tmp_path / "kokoro-v1.0.onnx"))
+    monkeypatch.delenv("KOKORO_VOICES_PATH", raising=False)
+    pth, cfg, vo = W.find_model_files(None, None)
+    assert pth == str(tmp_path / "kokoro-v1_0.pth") and cfg == str(tmp_path / "config.json") and vo == str(npz)
+
+
+def test_kokoro_missing_model_raises_not_aborts(tmp_path):
+    from tts_amd.kokoro import Kokoro
+    with pytest.raises(FileNotFoundError):
+        Kokoro(str(tmp_path / "kokoro-v1.0.onnx"), str(tmp_path / "voices-v1.0.bin"))
+    with pytest.raises(NotImplementedError):
+        Kokoro.from_session(object(), "voices.json")
+
+
+# ------------------------------------------------------------------ scheduler
+def test_sharding_and_batching_cover_every_sentence_once():
+    rng = np.random.default_rng(0)
+    counts = rng.integers(3, 400, size=301).tolist()
+    for world in (1, 2, 8):
+        shards = S.shard_sentences(counts, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(counts)))
+        cost = [float(S.estimate_cost([counts[i] for i in s]).sum()) for s in shards]
+        assert max(cost) / (sum(cost) / world) < 1.05               # LPT balance
+        for s in shards:
+            batches = S.make_batches(s, counts, max_batch=64, max_tokens=64 * 256)
+            assert sorted(i for b in batches for i in b) == s
+            for b in batches:
+                assert len(b) <= 64 and max(counts[i] for i in b) * len(b) <= 64 * 256
+                assert len({S.bucket_of(counts[i]) for i in b}) == 1
+    assert S.bucket_of(2) == 32 and S.bucket_of(512) == 512
+    with pytest.raises(ValueError):
+        S.bucket_of(513)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts = [5 + (i * 37) % 200 for i in range(n)]
+    mine = S.shard_sentences(counts, world)[rank]
+    local = {i: (np.full(600 * (counts[i] % 7 + 1), i, np.float32), np.array([counts[i]])) for i in mine}
+    res = S.ordered_gather(local, n)
+    if rank == 0:
+        q.put([(int(a[0][0]), a[0].shape[0], int(a[1][0])) for a in res])
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_gather_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, port = 23, _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts = [5 + (i * 37) % 200 for i in range(n)]
+    assert got == [(i, 600 * (counts[i] % 7 + 1), counts[i]) for i in range(n)]    # strictly by sentence index

@@ -251,3 +251,73 @@ def test_pcm16_matches_numpy(engine):
     got = engine.pcm16(x)
     ref = (np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2")     # basic.tts_kokoro_2_play_pause_works.py:25
     assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------ committed golden vector
+def test_engine_matches_committed_golden(engine):
+    """tests/golden/synthetic_T14.npz (tools/make_golden.py, CPU oracle): durations bit-exact,
+    token-rate stages and F0 within fp32 noise."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "synthetic_T14.npz"))
+    ids = g["ids"][None].astype(np.int64)
+    lens = np.array([ids.shape[1]], dtype=np.int32)
+    engine.debug_enable(True)
+    try:
+        pred, nfr = engine.durations(ids, lens, g["ref_s"][None])
+        assert np.array_equal(pred[0], g["pred_dur"])
+        audio, off = engine.decode(seeds=np.array([int(g["noise_seed"])], dtype=np.uint64))
+        assert audio.size == int(g["audio_len"])
+        T, F = int(lens[0]), int(nfr[0])
+        assert np.abs(engine.debug_get("duration")[0, 0, :T] - g["duration"]).max() < 5e-4
+        assert np.abs(engine.debug_get("d")[0][:, :T].T - g["d"]).max() < 1e-3
+        assert np.abs(engine.debug_get("t_en")[0][:, :T] - g["t_en"]).max() < 1e-4
+        assert np.abs(engine.debug_get("F0")[0, 0, :2 * F] - g["F0"]).max() < 5e-2
+    finally:
+        engine.debug_enable(False)
+
+
+# ------------------------------------------------------------------ the two front doors
+def test_kokoro_front_door(engine):
+    import threading
+    from tts_amd import Kokoro
+    k = Kokoro("synthetic", None)
+    assert k.get_voices() == ["af_synthetic"]
+    samples, sr = k.create("This is the 1st sentence. This is 2nd sentence.", voice="af_synthetic", speed=1.0,
+                           lang="en-us")                                   # basic.tts_kokoro.py:30
+    assert sr == 24000 and samples.dtype == np.float32 and samples.ndim == 1 and samples.size > 2400
+    assert np.isfinite(samples).all()
+    # phoneme input, no trim: length is exactly 600 * sum(pred_dur), identical to the raw engine
+    ph = "hɛlˈoʊ wɜːld"
+    s2, _ = k.create(ph, voice=k.get_voice_style("af_synthetic"), is_phonemes=True, trim=False)
+    from tts_amd import text as T
+    ids = T.tokenize(ph)
+    pred, nfr = engine.durations(*engine.pack([ids]), T.style_row(k.voices["af_synthetic"], len(ids), "kokoro_onnx")[None])
+    assert s2.size == 600 * int(nfr[0])
+    with pytest.raises(AssertionError):
+        k.create("x", voice="af_synthetic", speed=3.0)
+    with pytest.raises(KeyError):
+        k.create("x", voice="no_such_voice")
+    # two threads on one object (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715)
+    out = {}
+
+    def work(i):
+        out[i] = k.create(f"Sentence number {i} is spoken here.", voice="af_synthetic")[0]
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(out) == 4 and all(np.isfinite(v).all() and v.size > 0 for v in out.values())
+
+
+def test_kpipeline_front_door():
+    from tts_amd import KModel, KPipeline
+    model = KModel(model="synthetic")
+    pipe = KPipeline(lang_code="a", model=model)
+    res = list(pipe("First line of text.\nSecond line!", voice="af_heart", speed=1))
+    assert len(res) == 2
+    for gs, ps, audio in res:
+        assert isinstance(gs, str) and isinstance(ps, str) and audio.dtype == torch.float32 and audio.numel() > 0
+    assert res[0].graphemes == "First line of text." and res[0].pred_dur.sum() * 600 == res[0].audio.numel()
+    out = model("hɛlˈoʊ", torch.from_numpy(spec.synthetic_voice_pack(2)[4]), speed=1, return_output=True)
+    assert out.audio.numel() == 600 * int(out.pred_dur.sum()) and len(out.pred_dur) == 8
+    quiet = KPipeline(lang_code="a", model=False)
+    assert [r.audio for r in quiet("Only phonemes.")] == [None]

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void src_har_kernel(const float* f0, long fbs,
     if (n >= 600 * F) return;
     const int nlo = 2 * F;
     const float scale = (float)(1.0 / 300.0);
-    float src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)n, 0.5f)), 0.5f);
+    // torch's CPU upsample_linear1d fuses these two multiply-adds (oracle: sinegen_phase)
+    float src = __fmaf_rn(scale, __fadd_rn((float)n, 0.5f), -0.5f);
     src = fmaxf(src, 0.0f);
     const int i0 = (int)floorf(src);
     const float lam = __fsub_rn(src, (float)i0);
@@ -102,9 +103,8 @@ __global__ __launch_bounds__(256) void src_har_kernel(const float* f0, long fbs,
     float acc = 0.f;
 #pragma unroll
     for (int h = 0; h < K82_HARM; ++h) {
-        const float a = __fmul_rn(w0, pb[(long)h * ppitch + i0]);
         const float c = __fmul_rn(lam, pb[(long)h * ppitch + i1]);
-        const float phase = __fadd_rn(a, c);
+        const float phase = __fmaf_rn(w0, pb[(long)h * ppitch + i0], c);
         const float sine = __fmul_rn(sinf(phase), 0.1f);
         const float z = nz ? nz[h] : k82_noise_normal(base, (uint64_t)n, h);
         const float sw = __fadd_rn(__fmul_rn(sine, uv), __fmul_rn(namp, z));

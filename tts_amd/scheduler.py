@@ -1,0 +1,124 @@
+"""Sentence-level data parallelism: bucketing, sharding, batching, ordered gather.
+
+The reference synthesizes one sentence per ``create`` call, in any order, and re-assembles by
+index (basic.tts_kokoro_2_play_pause_works.py:85-124 keeps a reorder buffer keyed by sentence
+number).  Sentences are independent, so the node-level strategy is pure data parallelism: every
+GPU gets whole sentences, length-bucketed so padding stays small, and the only exchange is the
+final ordered gather of variable-length audio.  No collective touches the forward pass.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import spec
+
+BUCKET_EDGES = (32, 64, 128, 256, 512)       # token-count buckets
+
+
+def estimate_cost(n_tokens, frames_per_token: float = 3.5):
+    """Relative FLOP estimate of one sentence (SURVEY.md 8a totals): 79 M MAC per token plus
+    attention, 660 M MAC per predicted frame."""
+    t = np.asarray(n_tokens, dtype=np.float64)
+    return t * (79.0e6 + 18.4e3 * t) + t * frames_per_token * 660.0e6
+
+
+def bucket_of(n_tokens: int) -> int:
+    for e in BUCKET_EDGES:
+        if n_tokens <= e:
+            return e
+    raise ValueError(f"{n_tokens} tokens exceed the 512-token context")
+
+
+def shard_sentences(token_counts, world: int):
+    """Greedy longest-processing-time assignment: returns ``world`` index lists.  Deterministic
+    (ties broken by index), every rank computes the same partition without communicating."""
+    cost = estimate_cost(token_counts)
+    order = sorted(range(len(cost)), key=lambda i: (-cost[i], i))
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += float(cost[i])
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def make_batches(indices, token_counts, max_batch: int = 64, max_tokens: int = 64 * 256):
+    """Group a rank's sentences into batches of similar length: sort by bucket then length, cut
+    when the PADDED token count (batch x longest) or the batch size would exceed the limits."""
+    idx = sorted(indices, key=lambda i: (bucket_of(token_counts[i]), token_counts[i], i))
+    batches, cur, cur_max = [], [], 0
+    for i in idx:
+        t = token_counts[i]
+        new_max = max(cur_max, t)
+        if cur and (len(cur) + 1 > max_batch or new_max * (len(cur) + 1) > max_tokens
+                    or bucket_of(t) != bucket_of(token_counts[cur[0]])):
+            batches.append(cur)
+            cur, new_max = [], t
+        cur.append(i)
+        cur_max = new_max
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+class BatchSynthesizer:
+    """Runs lists of phoneme-id sentences through one Engine in length-bucketed batches and
+    returns audio per sentence, in input order."""
+
+    def __init__(self, engine, max_batch: int = 64, max_tokens: int = 64 * 256, frame_budget: int = 160_000):
+        self.engine = engine
+        self.max_batch, self.max_tokens, self.frame_budget = max_batch, max_tokens, frame_budget
+
+    def _run(self, id_lists, ref_rows, speeds, seeds, out, where):
+        ids, lens = self.engine.pack(id_lists)
+        pred, nfr = self.engine.durations(ids, lens, np.stack(ref_rows), speed=np.asarray(speeds, np.float32))
+        if int(nfr.sum()) > self.frame_budget and len(id_lists) > 1:       # bound the frame-rate workspace
+            h = len(id_lists) // 2
+            self._run(id_lists[:h], ref_rows[:h], speeds[:h], seeds[:h], out, where[:h])
+            self._run(id_lists[h:], ref_rows[h:], speeds[h:], seeds[h:], out, where[h:])
+            return
+        audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
+        for k, w in enumerate(where):
+            out[w] = (audio[off[k]:off[k + 1]].copy(), pred[k, :lens[k]].copy())
+
+    def synthesize(self, id_lists, ref_rows, speeds=None, seeds=None, indices=None):
+        """-> {index: (audio f32[600 F], pred_dur i32[T])} for ``indices`` (default: all)."""
+        n = len(id_lists)
+        indices = list(range(n)) if indices is None else list(indices)
+        speeds = [1.0] * n if speeds is None else list(speeds)
+        seeds = list(range(n)) if seeds is None else list(seeds)
+        counts = [len(x) + 2 for x in id_lists]
+        out = {}
+        for batch in make_batches(indices, counts, self.max_batch, self.max_tokens):
+            self._run([id_lists[i] for i in batch], [ref_rows[i] for i in batch], [speeds[i] for i in batch],
+                      [seeds[i] for i in batch], out, batch)
+        return out
+
+
+def ordered_gather(local: dict, n_total: int, group=None, dst: int = 0):
+    """The one exchange of the path: rank ``dst`` receives every rank's {index: payload} and returns
+    the payloads as a list in sentence order (other ranks return None).  Host-side gather through
+    torch.distributed (gloo or RCCL-backed object gather); audio volume is ~96 kB per audio-second,
+    far below any link's capacity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [local[i] for i in range(n_total)]
+    rank = dist.get_rank(group)
+    bucket = [None] * dist.get_world_size(group) if rank == dst else None
+    dist.gather_object(local, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    missing = [i for i in range(n_total) if i not in merged]
+    if missing:
+        raise RuntimeError(f"ordered_gather: sentences {missing[:5]} were synthesized by no rank")
+    return [merged[i] for i in range(n_total)]
+
+
+def audio_seconds(audios) -> float:
+    return sum(a.shape[0] for a in audios) / float(spec.SAMPLE_RATE)
