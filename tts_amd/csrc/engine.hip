@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -1019,6 +1020,7 @@ int k82_op_conv1d(k82_handle* h, const float* x, const float* w, const float* bi
         const LenSpec ls{nullptr, 0, L};
         ConvP p = h->cp(cw, xd, (long)cw.cin_p * P, P, yd, (long)cout * P, P, ls, ls, B, L, dil);
         p.act = act; p.slope = slope; p.alpha = ad; p.inv_alpha = iad;
+        if (const char* e = getenv("K82_CONV_DBG")) p.dbg = atoi(e);
         launch_conv(p, h->st);
         if (iters > 1 || ms) {
             hipEvent_t a, b;

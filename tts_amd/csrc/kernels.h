@@ -42,6 +42,7 @@ struct ConvP {
     int up_s, up_cout_shift, up_off;
     const unsigned* tapmask;                   // per 64-row M tile: bitmask of non-zero taps (nullptr: all)
     int B, Lmax_out;                           // grid extents
+    int dbg;                                   // timing experiments only (K82_CONV_DBG): 1 no stores, 2 no x restage, 4 A from one address
 };
 void launch_conv(const ConvP& p, hipStream_t s);
 double conv_flops(const ConvP& p, const int* host_lens);   // algorithmic FLOPs of one launch
