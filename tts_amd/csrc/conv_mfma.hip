@@ -48,14 +48,24 @@ __device__ __forceinline__ float snake(float v, float al, float ial) {
     return fmaf(ial, sn * sn, v);
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvP p) {
+// EPI selects the epilogue at compile time (a load under a run-time flag, even a wave-uniform one,
+// makes hipcc branch around it and drain vmcnt(0) per element -- the 16 us/tile the first versions
+// of this kernel lost):
+//   EPI_PLAIN  y = (f(acc + bias)) * out_scale                               float4 stores along t
+//   EPI_RES    y = (f(acc + bias) + res) * out_scale                         + float4 residual loads
+//   EPI_ACC    as EPI_RES, then accbuf = (acc_init ? 0 : accbuf) + y * acc_scale; y optional
+//   EPI_SCALAR transposed-conv phase interleave (up_s) / x2 nearest residual (res_shift): dword path
+enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3 };
+
+template <int WM, int WN, int EPI, bool SNAKE>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN, KC = 16, WP = BN + 68, NW = WM * WN;
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
+    constexpr int PATCH = 32 * 36 + 64;        // per-wave epilogue patch [32][36] + the wave's 64 bias values
     static_assert(KC % NW == 0, "KC must be a multiple of the wave count");
-    __shared__ __attribute__((aligned(16))) float xs[2][KC * WP];
-    __shared__ __attribute__((aligned(16))) float patches[NW][32 * 36];
+    // ONE __shared__ object (a second one beside the staging array can cost a vmcnt(0) per k-step)
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * WP + NW * PATCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: Tile stays in SGPRs
     const int wm = wave / WN, wn = wave % WN;
@@ -65,6 +75,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvP p) {
     const int MT = p.cout_p / BM, NT = (p.Lmax_out + BN - 1) / BN;
     const int total = MT * NT * p.B, G = gridDim.x;
     const unsigned tapall = (p.taps >= 32) ? 0xffffffffu : ((1u << p.taps) - 1u);
+    float* const patch = lds + 2 * KC * WP + wave * PATCH;
+    float* const bsh = patch + 32 * 36;
 
     // ---- persistent tile walk: block g handles output tiles g, g+G, g+2G, ... (m fastest, so the
     // blocks that share an x tile run side by side); everything in Tile is wave-uniform
@@ -107,55 +119,51 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvP p) {
 
     float4 raw[CPW][NCOL];
     // raw global loads of one ci-tile (no transform yet): wave w takes channels w, w+NW, ...
+    // All loads are UNCONDITIONAL with clamped (always in-bounds) coordinates; validity is applied
+    // later with selects.
     auto load_tile = [&](const Tile& T, int ci0) {
         const float* xb = p.x + (long)T.b * p.xbs;
+        const int tlast = ((T.Lin - 1) >> 2) << 2;          // last aligned float4 that starts inside the row
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
-            const int ci = ci0 + wave + cc * NW;
+            const int ci = min(ci0 + wave + cc * NW, p.cin - 1);
             const float* xr = xb + (long)ci * p.xpitch;
-            const bool cvalid = ci < p.cin;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const int col = 4 * (lane + 64 * k);
-                const int t = T.tbase + col;
-                raw[cc][k] = (cvalid && col < T.W && t >= 0 && t < T.Lin) ? *reinterpret_cast<const float4*>(xr + t)
-                                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int t = min(max(T.tbase + 4 * (lane + 64 * k), 0), tlast);
+                raw[cc][k] = *reinterpret_cast<const float4*>(xr + t);
             }
         }
     };
-    // transform (AdaIN affine, activation) and write to the LDS buffer; zero padding stays zero
+    // transform (AdaIN affine, activation) and write to the LDS buffer; zero padding stays zero.
+    // Branch-free per element: "no transform" is the affine (0, 1, 1, 0), TR_SCALE is (0, s, 1, 0),
+    // "no activation" is LeakyReLU with slope 1 -- all exact identities in fp32 -- and Snake is a
+    // template parameter, so the only branches left are the wave-uniform ones around scalar loads.
+    const float slope = (p.act == ACT_LEAKY) ? p.slope : 1.f;
     auto write_tile = [&](const Tile& T, int ci0, float* dst) {
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const int c = wave + cc * NW;
             const int ci = ci0 + c;
             const bool cvalid = ci < p.cin;
-            float4 nm = make_float4(0.f, 1.f, 1.f, 0.f);
+            float4 nm = make_float4(0.f, p.tr == TR_SCALE ? p.in_scale : 1.f, 1.f, 0.f);
             float al = 1.f, ial = 1.f;
-            if (cvalid) {
-                if (p.tr == TR_NORM) nm = p.norm[(long)T.b * p.nstride + ci];
-                if (p.act == ACT_SNAKE) { al = p.alpha[ci]; ial = p.inv_alpha[ci]; }
-            }
+            const int cic = min(ci, p.cin - 1);
+            if (p.tr == TR_NORM) nm = p.norm[(long)T.b * p.nstride + cic];       // wave-uniform, scalar loads
+            if constexpr (SNAKE) { al = p.alpha[cic]; ial = p.inv_alpha[cic]; }
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 const int col = 4 * (lane + 64 * k);
                 const int t = T.tbase + col;
-                if (col < T.W) {
-                    float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
+                float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float u = 0.f;
-                        if (cvalid && t + e >= 0 && t + e < T.Lin) {
-                            u = v[e];
-                            if (p.tr == TR_NORM) u = ((u - nm.x) * nm.y) * nm.z + nm.w;
-                            else if (p.tr == TR_SCALE) u = u * p.in_scale;
-                            if (p.act == ACT_LEAKY) u = u < 0.f ? u * p.slope : u;
-                            else if (p.act == ACT_SNAKE) u = snake(u, al, ial);
-                        }
-                        v[e] = u;
-                    }
-                    *reinterpret_cast<float4*>(dst + c * WP + col) = make_float4(v[0], v[1], v[2], v[3]);
+                for (int e = 0; e < 4; ++e) {
+                    float u = ((v[e] - nm.x) * nm.y) * nm.z + nm.w;
+                    if constexpr (SNAKE) u = snake(u, al, ial);
+                    else u = u < 0.f ? u * slope : u;
+                    v[e] = (cvalid && t + e >= 0 && t + e < T.Lin) ? u : 0.f;    // v_cndmask, no branch
                 }
+                if (col < WP) *reinterpret_cast<float4*>(dst + c * WP + col) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     };
@@ -183,88 +191,98 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvP p) {
     };
 
     // ---- epilogue of one output tile.  D layout: column j = lane&31 (t), row i = (r&3) + 8*(r>>2)
-    // + 4*(lane>>5) (co).  Plain convs send each 32x32 accumulator tile through a per-wave LDS patch
-    // ([32][36] floats) and read it back as float4 along t: 4 dwordx4 stores of 8 rows x 128 B per
-    // tile instead of 16 dword stores, and float4 residual / running-mean traffic.  The stores are
-    // asynchronous: the wave goes straight on to the MFMAs of its next tile.
-    auto epilogue = [&](const Tile& T) {
+    // + 4*(lane>>5) (co).  The wide epilogues send each 32x32 accumulator tile through the wave's LDS
+    // patch and read it back as float4 along t: 4 dwordx4 stores of 8 rows x 128 B per tile, float4
+    // residual / running-mean traffic; the residual loads of 32x32 tile i+1 are in flight while tile i
+    // is finished.  Rows are padded to a multiple of 4 floats and nothing downstream reads the padding
+    // (every consumer masks by length), so a float4 that starts inside the row is stored whole.
+    // bias_l = bias[m0 + lane] was loaded at the start of the tile and reaches the lanes through LDS.
+    auto epilogue = [&](const Tile& T, float bias_l) {
         const long yb = (long)T.b * p.ybs, rb = (long)T.b * p.rbs, ab = (long)T.b * p.abs_;
-        const bool wide = p.up_s == 0 && p.res_shift == 0;
-        if (wide) {
-            float* patch = patches[wave];
+        bsh[lane] = bias_l;
+        if constexpr (EPI != EPI_SCALAR) {
+            const int i0 = lane >> 3, c4 = (lane & 7) * 4;
+            const int tl = ((T.Lout - 1) >> 2) << 2;
+            float4 r4[2][4], a4[2][4];
+            auto issue = [&](int idx, float4 (&r)[4], float4 (&a)[4]) {
+                const int mi = idx >> 1, ni = idx & 1;
+                const int tc = min(T.n0 + nw + ni * 32 + c4, tl);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mc = min(T.m0 + mi * 32 + i0 + 8 * q, p.cout - 1);
+                    if constexpr (EPI >= EPI_RES) r[q] = *reinterpret_cast<const float4*>(p.res + rb + (long)mc * p.rpitch + tc);
+                    if constexpr (EPI == EPI_ACC) a[q] = *reinterpret_cast<const float4*>(p.accbuf + ab + (long)mc * p.apitch + tc);
+                }
+            };
+            issue(0, r4[0], a4[0]);
+#pragma unroll
+            for (int idx = 0; idx < 4; ++idx) {
+                const int mi = idx >> 1, ni = idx & 1;
+                if (idx + 1 < 4) issue(idx + 1, r4[(idx + 1) & 1], a4[(idx + 1) & 1]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
+                const int t = T.n0 + nw + ni * 32 + c4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + 8 * q;
+                    const float4 v4 = *reinterpret_cast<const float4*>(patch + i * 36 + c4);
+                    const float bs = bsh[mi * 32 + i];
+                    const int m = T.m0 + mi * 32 + i;
+                    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                    float rs[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI >= EPI_RES) { const float4 u = r4[idx & 1][q]; rs[0] = u.x; rs[1] = u.y; rs[2] = u.z; rs[3] = u.w; }
+                    if constexpr (EPI == EPI_ACC) {
+                        const float4 u = a4[idx & 1][q];
+                        av[0] = p.acc_init ? 0.f : u.x; av[1] = p.acc_init ? 0.f : u.y;
+                        av[2] = p.acc_init ? 0.f : u.z; av[3] = p.acc_init ? 0.f : u.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = v[e] + bs;
+                        if (p.out_act == OACT_GELU_NEW) u = gelu_new(u);
+                        u = (u + rs[e]) * p.out_scale;
+                        v[e] = u;
+                        av[e] = av[e] + u * p.acc_scale;
+                    }
+                    if (m < p.cout && t < T.Lout) {             // stores only under the lane-dependent condition
+                        if (EPI != EPI_ACC || p.y)
+                            *reinterpret_cast<float4*>(p.y + yb + (long)m * p.ypitch + t) = make_float4(v[0], v[1], v[2], v[3]);
+                        if constexpr (EPI == EPI_ACC)
+                            *reinterpret_cast<float4*>(p.accbuf + ab + (long)m * p.apitch + t) = make_float4(av[0], av[1], av[2], av[3]);
+                    }
+                }
+            }
+        } else {
+            const int upmask = (1 << p.up_cout_shift) - 1;
+            const float* resp = p.res ? p.res + rb : p.bias;      // always a readable address: no branch per load
+            const int rpitch = p.res ? p.rpitch : 0;
+            const float rmul = p.res ? 1.f : 0.f;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
-                        const float4 v4 = *reinterpret_cast<const float4*>(patch + i * 36 + c4);
-                        const int m = T.m0 + mi * 32 + i;
-                        const int t = T.n0 + nw + ni * 32 + c4;
-                        if (m < p.cout && t < T.Lout && !((p.dbg & 1) && v4.x != 12345.678f)) {
-                            float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                            const float bs = p.bias ? p.bias[m] : 0.f;
-                            const bool full = t + 3 < T.Lout;
-                            float rs[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (p.res) {
-                                const float* rp = p.res + rb + (long)m * p.rpitch + t;
-                                if (full) { const float4 r4 = *reinterpret_cast<const float4*>(rp); rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w; }
-                                else for (int e = 0; e < 4; ++e) if (t + e < T.Lout) rs[e] = rp[e];
-                            }
-                            float* apn = p.accbuf ? p.accbuf + ab + (long)m * p.apitch + t : nullptr;
-                            if (apn && !p.acc_init) {
-                                if (full) { const float4 a4 = *reinterpret_cast<const float4*>(apn); av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w; }
-                                else for (int e = 0; e < 4; ++e) if (t + e < T.Lout) av[e] = apn[e];
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float u = v[e] + bs;
-                                if (p.out_act == OACT_GELU_NEW) u = gelu_new(u);
-                                u = (u + rs[e]) * p.out_scale;
-                                v[e] = u;
-                                av[e] = av[e] + u * p.acc_scale;
-                            }
-                            if (p.y) {
-                                float* yp = p.y + yb + (long)m * p.ypitch + t;
-                                if (full) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                                else for (int e = 0; e < 4; ++e) if (t + e < T.Lout) yp[e] = v[e];
-                            }
-                            if (apn) {
-                                if (full) *reinterpret_cast<float4*>(apn) = make_float4(av[0], av[1], av[2], av[3]);
-                                else for (int e = 0; e < 4; ++e) if (t + e < T.Lout) apn[e] = av[e];
-                            }
-                        }
-                    }
-                }
-            return;
-        }
-        const int upmask = (1 << p.up_cout_shift) - 1;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = T.m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     const int t = T.n0 + nw + ni * 32 + l31;
-                    if (m < p.cout && t < T.Lout && !((p.dbg & 1) && acc[mi][ni][r] != 12345.678f)) {
-                        float v = acc[mi][ni][r];
-                        if (p.bias) v += p.bias[m];
+                    const int tc = min(t, T.Lout - 1);
+                    float rv[16];
+                    int off[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mc = min(T.m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, p.cout - 1);
+                        int row = mc, col = tc;
+                        if (p.up_s) { row = mc & upmask; col = p.up_s * tc + (mc >> p.up_cout_shift) + p.up_off; }
+                        off[r] = row * p.ypitch + col;
+                        rv[r] = resp[p.res ? (long)row * rpitch + (col >> p.res_shift) : 0];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mrow = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        float v = acc[mi][ni][r] + bsh[mrow];
                         if (p.out_act == OACT_GELU_NEW) v = gelu_new(v);
-                        int row = m, col = t;
-                        if (p.up_s) { row = m & upmask; col = p.up_s * t + (m >> p.up_cout_shift) + p.up_off; }
-                        if (p.res) v += p.res[rb + (long)row * p.rpitch + (col >> p.res_shift)];
-                        v *= p.out_scale;
-                        if (p.y) p.y[yb + (long)row * p.ypitch + col] = v;
-                        if (p.accbuf) {
-                            float* a = p.accbuf + ab + (long)row * p.apitch + col;
-                            *a = (p.acc_init ? 0.f : *a) + v * p.acc_scale;
-                        }
+                        v = (v + rv[r] * rmul) * p.out_scale;
+                        if (T.m0 + mrow < p.cout && t < T.Lout) p.y[yb + off[r]] = v;
                     }
                 }
+        }
     };
 
     // ---- the flattened (output tile, ci-tile, active tap) step sequence.  Step s consumes the A
@@ -276,24 +294,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvP p) {
     int q = next_valid(blockIdx.x, cur);
     if (q < 0) return;
     load_tile(cur, 0);
-    write_tile(cur, 0, xs[0]);
+    write_tile(cur, 0, lds);
     load_a(cur, 0, cur.tap0, a0);
     __syncthreads();
     int g = 0;                                   // parity of the LDS buffer holding the current ci-tile
     while (true) {
         const int qn = next_valid(q + G, nxt);
         const bool have_next = qn >= 0;
+        const float bias_l = p.bias[cur.m0 + lane];          // bias is padded to cout_p; lands during the main loop
         zero_acc();
         int tap = cur.tap0;
         for (int it = 0; it < ntiles; ++it) {
             const int ci0 = it * KC;
             const bool more = it + 1 < ntiles;
-            const float* xsb = xs[g & 1];
-            float* xsn = xs[(g + 1) & 1];
+            const float* xsb = lds + (g & 1) * (KC * WP);
+            float* xsn = lds + ((g + 1) & 1) * (KC * WP);
             for (int j = 0; j < cur.nact; ++j) {
                 const bool last_in_tile = (j == cur.nact - 1);
                 // one call site each for load_tile / load_a / write_tile (they inline large bodies)
-                const bool stage = j == 0 && (more || have_next) && !(p.dbg & 2);
+                const bool stage = j == 0 && (more || have_next);
                 const Tile& S = more ? cur : nxt;
                 const int sci0 = more ? ci0 + KC : 0;
                 if (stage) load_tile(S, sci0);
@@ -315,23 +334,41 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvP p) {
             __syncthreads();
             ++g;
         }
-        epilogue(cur);
+        epilogue(cur, bias_l);
         if (!have_next) break;
         cur = nxt;
         q = qn;
     }
 }
 
+template <int WM, int WN, bool SNAKE>
+static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
+    switch (epi) {
+    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_PLAIN, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_RES, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_ACC, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
+    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_SCALAR, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
+    }
+}
+template <int WM, int WN>
+static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
+    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true>(p, epi, grid, s);
+    else launch_epi<WM, WN, false>(p, epi, grid, s);
+}
+
 // Persistent launch: at most CUS x BLOCKS_PER_CU workgroups walk the output tiles.
+// Host-checked operand contract (engine.hip run_conv): bias != nullptr and padded to cout_p; accbuf implies
+// res and a wide epilogue; y != nullptr unless accbuf; all pitches % 4 == 0 and bases 16-byte aligned.
 void launch_conv(const ConvP& p, hipStream_t s) {
     if (p.Lmax_out <= 0 || p.B <= 0) return;
     const int kMaxBlocks = 256 * 2;
+    const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
-        hipLaunchKernelGGL((conv_mfma_kernel<2, 2>), dim3((unsigned)(total < kMaxBlocks ? total : kMaxBlocks)), dim3(256), 0, s, p);
+        launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
-        hipLaunchKernelGGL((conv_mfma_kernel<1, 4>), dim3((unsigned)(total < kMaxBlocks ? total : kMaxBlocks)), dim3(256), 0, s, p);
+        launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     }
 }
 

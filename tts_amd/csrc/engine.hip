@@ -214,11 +214,9 @@ struct k82_handle {
                 for (int kk = 0; kk < k; ++kk)
                     t[((size_t)kk * c.cin_p + ci) * c.cout_p + co] = W[((size_t)co * cin + ci) * k + kk];
         c.w = upload(t);
-        if (bias) {
-            std::vector<float> bp(c.cout_p, 0.f);
-            std::copy(bias->begin(), bias->end(), bp.begin());
-            c.bias = upload(bp);
-        }
+        std::vector<float> bp(c.cout_p, 0.f);        // always present, padded to cout_p (the kernel loads it unconditionally)
+        if (bias) std::copy(bias->begin(), bias->end(), bp.begin());
+        c.bias = upload(bp);
         return c;
     }
     ConvW mk_conv(const std::string& prefix, int cout, int cin, int k, bool has_bias = true) {
@@ -446,8 +444,19 @@ struct k82_handle {
         p.B = nb; p.Lmax_out = Lmax;
         return p;
     }
-    void run_conv(const ConvP& p, const int* host_base) {
+    // operand shapes the kernel and its grid assume (conv_mfma.hip launch_conv), checked before every launch
+    static void check_conv(const ConvP& p) {
         REQUIRE((p.taps - 1) * p.dil <= 64, K82_EINVAL, "conv halo exceeds the LDS tile");
+        REQUIRE(p.x && p.w && p.bias && (p.y || p.accbuf), K82_EINVAL, "conv operand missing");
+        REQUIRE(p.cin_p % 16 == 0 && p.cout_p % 64 == 0 && p.cin <= p.cin_p && p.cout <= p.cout_p, K82_EINVAL, "conv channel padding");
+        REQUIRE(p.xpitch % 4 == 0 && (!p.y || p.ypitch % 4 == 0) && (!p.res || p.res_shift || p.up_s || p.rpitch % 4 == 0) &&
+                (!p.accbuf || p.apitch % 4 == 0), K82_EINVAL, "conv row pitch must be a multiple of 4 floats");
+        REQUIRE(!p.accbuf || (p.res && !p.up_s && !p.res_shift), K82_EINVAL, "accumulating epilogue needs a residual and a plain layout");
+        REQUIRE(p.act != ACT_SNAKE || (p.alpha && p.inv_alpha), K82_EINVAL, "snake needs alpha");
+        REQUIRE(p.tr != TR_NORM || p.norm, K82_EINVAL, "norm transform needs statistics");
+    }
+    void run_conv(const ConvP& p, const int* host_base) {
+        check_conv(p);
         const int fam = (p.cout_p % 128 == 0) ? FAM_CONV22 : FAM_CONV14;
         double work = 0;
         if (prof_on) work = conv_flops(p, p.lout.lens ? host_base : nullptr);
@@ -1020,7 +1029,7 @@ int k82_op_conv1d(k82_handle* h, const float* x, const float* w, const float* bi
         const LenSpec ls{nullptr, 0, L};
         ConvP p = h->cp(cw, xd, (long)cw.cin_p * P, P, yd, (long)cout * P, P, ls, ls, B, L, dil);
         p.act = act; p.slope = slope; p.alpha = ad; p.inv_alpha = iad;
-        if (const char* e = getenv("K82_CONV_DBG")) p.dbg = atoi(e);
+        k82_handle::check_conv(p);
         launch_conv(p, h->st);
         if (iters > 1 || ms) {
             hipEvent_t a, b;
