@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libk82.so")
+# K82_LIB_PATH: A/B timing of kernel variants only (tools/ab_conv.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("K82_LIB_PATH") or os.path.join(_HERE, "libk82.so")
 
 K82_OK, K82_ENOSPC = 0, -28
 

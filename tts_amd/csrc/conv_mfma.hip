@@ -117,7 +117,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
 
-    float4 raw[CPW][NCOL];
+    float4 raw[CPW][NCOL], nmr[CPW];
+    float alr[CPW], ialr[CPW];
+    // Per-channel transform parameters always come from a readable address (the padded bias vector stands
+    // in when there is no AdaIN / Snake), so they are prefetched unconditionally with the tile.
+    const float4* const normp = (p.tr == TR_NORM) ? p.norm : reinterpret_cast<const float4*>(p.bias);
+    const int nstride = (p.tr == TR_NORM) ? p.nstride : 0, nclamp = (p.tr == TR_NORM) ? p.cin - 1 : 0;
+    const float4 nid = make_float4(0.f, p.tr == TR_SCALE ? p.in_scale : 1.f, 1.f, 0.f);
+    const float slope = (p.act == ACT_LEAKY) ? p.slope : 1.f;
     // raw global loads of one ci-tile (no transform yet): wave w takes channels w, w+NW, ...
     // All loads are UNCONDITIONAL with clamped (always in-bounds) coordinates; validity is applied
     // later with selects.
@@ -133,35 +140,37 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
                 const int t = min(max(T.tbase + 4 * (lane + 64 * k), 0), tlast);
                 raw[cc][k] = *reinterpret_cast<const float4*>(xr + t);
             }
+            nmr[cc] = normp[(long)T.b * nstride + min(ci, nclamp)];
+            if constexpr (SNAKE) { alr[cc] = p.alpha[ci]; ialr[cc] = p.inv_alpha[ci]; }
         }
     };
     // transform (AdaIN affine, activation) and write to the LDS buffer; zero padding stays zero.
     // Branch-free per element: "no transform" is the affine (0, 1, 1, 0), TR_SCALE is (0, s, 1, 0),
     // "no activation" is LeakyReLU with slope 1 -- all exact identities in fp32 -- and Snake is a
-    // template parameter, so the only branches left are the wave-uniform ones around scalar loads.
-    const float slope = (p.act == ACT_LEAKY) ? p.slope : 1.f;
+    // template parameter.
+    // VALU budget (the two waves of a SIMD share its vector issue, so every instruction here is paid twice
+    // when they run in step): the affine is folded to one fma per element (scale = rstd * (1 + gamma),
+    // offset = beta - mean * scale: within 2 ulp of the reference's (x - mean) * rstd * (1 + gamma) + beta),
+    // LeakyReLU is max(u, slope * u) (slope in [0, 1], checked on the host), validity is one unsigned
+    // compare against the row length (0 for padded channels).
     auto write_tile = [&](const Tile& T, int ci0, float* dst) {
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const int c = wave + cc * NW;
-            const int ci = ci0 + c;
-            const bool cvalid = ci < p.cin;
-            float4 nm = make_float4(0.f, p.tr == TR_SCALE ? p.in_scale : 1.f, 1.f, 0.f);
-            float al = 1.f, ial = 1.f;
-            const int cic = min(ci, p.cin - 1);
-            if (p.tr == TR_NORM) nm = p.norm[(long)T.b * p.nstride + cic];       // wave-uniform, scalar loads
-            if constexpr (SNAKE) { al = p.alpha[cic]; ial = p.inv_alpha[cic]; }
+            const unsigned lin = (ci0 + c < p.cin) ? (unsigned)T.Lin : 0u;
+            const float4 nm = (p.tr == TR_NORM) ? nmr[cc] : nid;
+            const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 const int col = 4 * (lane + 64 * k);
-                const int t = T.tbase + col;
+                const unsigned t = (unsigned)(T.tbase + col);
                 float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float u = ((v[e] - nm.x) * nm.y) * nm.z + nm.w;
-                    if constexpr (SNAKE) u = snake(u, al, ial);
-                    else u = u < 0.f ? u * slope : u;
-                    v[e] = (cvalid && t + e >= 0 && t + e < T.Lin) ? u : 0.f;    // v_cndmask, no branch
+                    float u = fmaf(v[e], sc, of);
+                    if constexpr (SNAKE) u = snake(u, alr[cc], ialr[cc]);
+                    else u = fmaxf(u, u * slope);
+                    v[e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
                 }
                 if (col < WP) *reinterpret_cast<float4*>(dst + c * WP + col) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -169,24 +178,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     };
 
     float a0[KC / 2][2], a1[KC / 2][2];     // A fragments of the tap being consumed / the next one
-    auto load_a = [&](const Tile& T, int ci0, int tap, float (&a)[KC / 2][2]) {
-        const float* wp = p.w + ((long)(tap * p.cin_p + ci0 + lhi) * p.cout_p) + T.m0 + l31;
+    auto load_a = [&](int m0, int ci0, int tap, float (&a)[KC / 2][2]) {
+        const float* wp = p.w + ((long)(tap * p.cin_p + ci0 + lhi) * p.cout_p) + m0 + l31;
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
             a[kk][0] = wp[(long)(2 * kk) * p.cout_p];
             a[kk][1] = wp[(long)(2 * kk) * p.cout_p + 32];
         }
     };
-    auto mfma_tap = [&](const float* xsb, int off, const float (&a)[KC / 2][2]) {
-        const float* xsp = xsb + lhi * WP + nw + l31 + off;
+    // a0 <- a1 through opaque moves.  With plain copies hipcc coalesces a1 into a0 across the loop; with a0
+    // loaded directly in the prologue its wait-count pass merges "a0 may still be in flight" into the loop
+    // header.  Either way the MFMAs of a step end up waiting (in-order vmcnt) for the x and A loads issued
+    // just before them -- one exposed memory round trip per ci-tile.  The moves pin the wait to the end of
+    // the step, ~2000 cycles after the loads were issued.
+    auto rotate_a = [&]() {
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
-            const float b0 = xsp[2 * kk * WP];
-            const float b1 = xsp[2 * kk * WP + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b1, acc[1][1], 0, 0, 0);
+            asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][0]) : "v"(a1[kk][0]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][1]) : "v"(a1[kk][1]));
+        }
+    };
+    // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
+    // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
+    auto mfma_tap = [&](const float* xsb, int off, const float (&a)[KC / 2][2]) {
+        const float* xsp = xsb + lhi * WP + nw + l31 + off;
+        float b[KC / 2][2];
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            b[kk][0] = xsp[2 * kk * WP];
+            b[kk][1] = xsp[2 * kk * WP + 32];
+        }
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b[kk][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b[kk][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b[kk][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b[kk][1], acc[1][1], 0, 0, 0);
         }
     };
 
@@ -285,51 +312,67 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
         }
     };
 
-    // ---- the flattened (output tile, ci-tile, active tap) step sequence.  Step s consumes the A
-    // fragments prefetched during step s-1; the raw x loads of the NEXT ci-tile (of this output
-    // tile, or the first ci-tile of the block's next output tile) are issued at the first tap of a
-    // ci-tile and transformed / written to the other LDS buffer right after that tap's MFMAs are
-    // issued; one barrier per ci-tile.  Nothing but the very first tile of a block starts cold.
+    // ---- the (output tile, ci-tile, active tap) step sequence.  Step s consumes the A fragments
+    // prefetched during step s-1.  The first tap of every ci-tile also stages x: the raw loads of the
+    // NEXT ci-tile (of this output tile, or the first ci-tile of the block's next output tile) are issued
+    // ahead of its MFMAs and transformed / written to the other LDS buffer right after them; one barrier
+    // per ci-tile.  The staging step is straight-line code on purpose -- no condition sits between the
+    // loads and their use (a conditional definition turns into PHI copies placed right behind the loads,
+    // i.e. a wait for them before the MFMAs).  At the very end of a block's walk "next" aliases the current
+    // tile, so the one redundant prefetch reads valid addresses and lands in the LDS buffer nobody reads.
     Tile cur, nxt;
     int q = next_valid(blockIdx.x, cur);
     if (q < 0) return;
     load_tile(cur, 0);
     write_tile(cur, 0, lds);
-    load_a(cur, 0, cur.tap0, a0);
+    load_a(cur.m0, 0, cur.tap0, a1);
+    rotate_a();
     __syncthreads();
     int g = 0;                                   // parity of the LDS buffer holding the current ci-tile
     while (true) {
         const int qn = next_valid(q + G, nxt);
         const bool have_next = qn >= 0;
+        if (!have_next) nxt = cur;
         const float bias_l = p.bias[cur.m0 + lane];          // bias is padded to cout_p; lands during the main loop
         zero_acc();
         int tap = cur.tap0;
+        auto next_tap = [&](int t) -> int {
+            const unsigned mm = (t >= 31) ? 0u : (cur.mask >> (t + 1));
+            return mm ? t + 1 + __builtin_ctz(mm) : cur.tap0;
+        };
         for (int it = 0; it < ntiles; ++it) {
             const int ci0 = it * KC;
             const bool more = it + 1 < ntiles;
             const float* xsb = lds + (g & 1) * (KC * WP);
             float* xsn = lds + ((g + 1) & 1) * (KC * WP);
-            for (int j = 0; j < cur.nact; ++j) {
-                const bool last_in_tile = (j == cur.nact - 1);
-                // one call site each for load_tile / load_a / write_tile (they inline large bodies)
-                const bool stage = j == 0 && (more || have_next);
-                const Tile& S = more ? cur : nxt;
-                const int sci0 = more ? ci0 + KC : 0;
-                if (stage) load_tile(S, sci0);
-                const bool intile = !last_in_tile || more;
-                const Tile& AT = intile ? cur : nxt;
-                int ntap = nxt.tap0;
-                if (intile) {
-                    const unsigned mm = (tap >= 31) ? 0u : (cur.mask >> (tap + 1));
-                    ntap = mm ? tap + 1 + __builtin_ctz(mm) : cur.tap0;
-                }
-                const int aci0 = !last_in_tile ? ci0 : (more ? ci0 + KC : 0);
-                if (intile || have_next) load_a(AT, aci0, ntap, a1);
+            Tile S;                                           // whose x tile / weights come next (by value:
+            S.b = more ? cur.b : nxt.b;                       // a reference to "cur or nxt" sends both to scratch)
+            S.m0 = more ? cur.m0 : nxt.m0;
+            S.Lin = more ? cur.Lin : nxt.Lin;
+            S.tbase = more ? cur.tbase : nxt.tbase;
+            S.tap0 = more ? cur.tap0 : nxt.tap0;
+            const int sci0 = more ? ci0 + KC : 0;
+            {   // first active tap: stage + compute
+                const bool single = cur.nact == 1;
+                const int ntap = single ? S.tap0 : next_tap(tap);
+                load_tile(S, sci0);
+                load_a(single ? S.m0 : cur.m0, single ? sci0 : ci0, ntap, a1);
+                __builtin_amdgcn_sched_barrier(0);     // loads are issued BEFORE the MFMAs (the scheduler sinks them otherwise)
                 mfma_tap(xsb, tap * p.dil + cur.shift, a0);
-                if (stage) write_tile(S, sci0, xsn);
+                __builtin_amdgcn_sched_barrier(0);     // ... and waited for only after the MFMAs are in the pipe
+                write_tile(S, sci0, xsn);
                 tap = ntap;
-#pragma unroll
-                for (int kk = 0; kk < KC / 2; ++kk) { a0[kk][0] = a1[kk][0]; a0[kk][1] = a1[kk][1]; }
+                rotate_a();
+            }
+            for (int j = 1; j < cur.nact; ++j) {
+                const bool last = j == cur.nact - 1;
+                const int ntap = last ? S.tap0 : next_tap(tap);
+                load_a(last ? S.m0 : cur.m0, last ? sci0 : ci0, ntap, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(xsb, tap * p.dil + cur.shift, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                tap = ntap;
+                rotate_a();
             }
             __syncthreads();
             ++g;

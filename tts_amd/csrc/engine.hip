@@ -453,6 +453,7 @@ struct k82_handle {
                 (!p.accbuf || p.apitch % 4 == 0), K82_EINVAL, "conv row pitch must be a multiple of 4 floats");
         REQUIRE(!p.accbuf || (p.res && !p.up_s && !p.res_shift), K82_EINVAL, "accumulating epilogue needs a residual and a plain layout");
         REQUIRE(p.act != ACT_SNAKE || (p.alpha && p.inv_alpha), K82_EINVAL, "snake needs alpha");
+        REQUIRE(p.act != ACT_LEAKY || (p.slope >= 0.f && p.slope <= 1.f), K82_EINVAL, "LeakyReLU slope must be in [0, 1]");
         REQUIRE(p.tr != TR_NORM || p.norm, K82_EINVAL, "norm transform needs statistics");
     }
     void run_conv(const ConvP& p, const int* host_base) {
