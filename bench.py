@@ -108,6 +108,14 @@ def main():
     finite = bool(torch.isfinite(audio_d).all().item())
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel family come from the committed rocprofv3 PMC passes of this
+        # same command (counters cannot be read from inside the process); see profiles/*_traffic.json.
+        traffic, traffic_src = None, None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v2_traffic.json")
+        if os.path.exists(tp) and B == 64 and T == 256:
+            with open(tp) as fh:
+                traffic = json.load(fh)["conv_mfma_2x2_family"]["traffic_bytes_per_launch_corrected"]
+            traffic_src = "profiles/r01_v2_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes"
         out = {
             "metric": "audio-sec synthesized/sec (node) Kokoro-82M",
             "value": audio_all * args.steps / dt,
@@ -133,7 +141,8 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if conv_ms > 0 else None,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches_per_step": conv_n / args.steps,
                 "avg_launch_ms": conv_ms / conv_n if conv_n else None,
                 "ms_per_step": conv_ms / args.steps,

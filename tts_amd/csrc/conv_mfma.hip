@@ -321,6 +321,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     // i.e. a wait for them before the MFMAs).  At the very end of a block's walk "next" aliases the current
     // tile, so the one redundant prefetch reads valid addresses and lands in the LDS buffer nobody reads.
     Tile cur, nxt;
+    // Tile walk start.  (An XCD-aware renumbering -- the 64 workgroups of one XCD, b % 8, walking consecutive
+    // tiles so halo and shared x tiles stay behind one L2 -- measured 1-6 % SLOWER on the same box than this
+    // round-robin order, which spreads neighbouring tiles over all eight L2s and memory channels; kept simple.)
     int q = next_valid(blockIdx.x, cur);
     if (q < 0) return;
     load_tile(cur, 0);
