@@ -87,33 +87,48 @@ class Kokoro:
             raise KeyError(f"voice '{name}' not found; available: {self.get_voices()[:8]}...")
         return self.voices[name]
 
+    def _prepare(self, text, voice, lang, is_phonemes):
+        """text -> (token-id lists of its <= 510-phoneme chunks, style rows)."""
+        phonemes = text if is_phonemes else T.phonemize(text, lang)[0]
+        chunks = T.split_phonemes(phonemes) or [""]
+        id_lists = [T.tokenize(ch[:T.MAX_PHONEME_LENGTH], self.vocab)[:T.MAX_PHONEME_LENGTH] for ch in chunks]
+        rows = [T.style_row(voice, len(ids), "kokoro_onnx") for ids in id_lists]
+        return id_lists, rows
+
+    def create_batch(self, texts, voice, speed: float = 1.0, lang: str = "en-us", is_phonemes: bool = False,
+                     trim: bool = True):
+        """``[create(t, ...) for t in texts]`` as ONE scheduled engine pass (all chunks of all texts are
+        bucketed and batched together).  Not in kokoro_onnx: it is what the read-aloud look-ahead window
+        (tts_amd/readaloud.py) and whole-chapter export use, because on the GPU a batch costs about what one
+        sentence does.  Same validation, chunking, style-row and trim rules as ``create``."""
+        assert 0.5 <= speed <= 2.0, "Speed should be between 0.5 and 2.0"
+        if isinstance(voice, str):
+            voice = self.get_voice_style(voice)
+        voice = np.asarray(voice, dtype=np.float32)
+        id_lists, rows, owner = [], [], []
+        for ti, text in enumerate(texts):
+            ids, rs = self._prepare(text, voice, lang, is_phonemes)
+            id_lists += ids
+            rows += rs
+            owner += [ti] * len(ids)
+        with self._seed_lock:
+            seeds = [self._seed + i for i in range(len(id_lists))]
+            self._seed += len(id_lists)
+        res = self.synth.synthesize(id_lists, rows, speeds=[float(speed)] * len(id_lists), seeds=seeds)
+        parts = [[] for _ in texts]
+        for i, ti in enumerate(owner):
+            a = res[i][0]
+            if trim:
+                a, _ = T.trim_audio(a)
+            parts[ti].append(a)
+        return [(np.concatenate(p).astype(np.float32), SAMPLE_RATE) for p in parts]
+
     def create(self, text, voice, speed: float = 1.0, lang: str = "en-us", is_phonemes: bool = False,
                trim: bool = True):
         """-> (samples float32[N] in [-1, 1], 24000).  Same contract as the reference boundary
         (speech7.py:127): phonemize, chunk to <= 510 phonemes, synthesize each chunk with the
         style row ``voice[len(tokens)]``, optionally trim silence, concatenate."""
-        assert 0.5 <= speed <= 2.0, "Speed should be between 0.5 and 2.0"
-        if isinstance(voice, str):
-            voice = self.get_voice_style(voice)
-        voice = np.asarray(voice, dtype=np.float32)
-        phonemes = text if is_phonemes else T.phonemize(text, lang)[0]
-        chunks = T.split_phonemes(phonemes) or [""]
-        id_lists = []
-        for ch in chunks:
-            ids = T.tokenize(ch[:T.MAX_PHONEME_LENGTH], self.vocab)[:T.MAX_PHONEME_LENGTH]
-            id_lists.append(ids)
-        rows = [T.style_row(voice, len(ids), "kokoro_onnx") for ids in id_lists]
-        with self._seed_lock:
-            seeds = [self._seed + i for i in range(len(id_lists))]
-            self._seed += len(id_lists)
-        res = self.synth.synthesize(id_lists, rows, speeds=[float(speed)] * len(id_lists), seeds=seeds)
-        parts = []
-        for i in range(len(id_lists)):
-            a = res[i][0]
-            if trim:
-                a, _ = T.trim_audio(a)
-            parts.append(a)
-        return np.concatenate(parts).astype(np.float32), SAMPLE_RATE
+        return self.create_batch([text], voice, speed, lang, is_phonemes, trim)[0]
 
 
 # ------------------------------------------------------------------------------ surface B
