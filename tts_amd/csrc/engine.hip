@@ -37,14 +37,32 @@ inline int ru(int a, int m) { return (a + m - 1) / m * m; }
 std::string g_create_error;
 
 // grow-only chunked device arena: no hipMalloc in steady state
+// Grow-only bump allocator for activations.  A pass (one k82_durations / k82_decode call) that outgrows the
+// arena adds chunks on demand; the next reset() folds them into ONE chunk sized for the largest pass seen, so
+// a stream of differently sized batches neither fragments nor accumulates device memory (steady state: no
+// hipMalloc at all on the hot path).
 struct Arena {
     struct Chunk { char* p; size_t cap; };
     std::vector<Chunk> chunks;
     size_t cur = 0, off = 0, chunk_default = (size_t)256 << 20;
-    void reset() { cur = 0; off = 0; }
+    size_t pass_bytes = 0, high = 0;
+    void reset() {
+        high = std::max(high, pass_bytes);
+        if (chunks.size() > 1) {
+            (void)hipDeviceSynchronize();                   // nothing of the previous pass may still be running
+            for (auto& c : chunks) (void)hipFree(c.p);
+            chunks.clear();
+            Chunk c;
+            c.cap = high + high / 8 + ((size_t)64 << 20);
+            if (hipMalloc((void**)&c.p, c.cap) == hipSuccess) chunks.push_back(c);
+            else (void)hipGetLastError();                   // fall back to growing on demand
+        }
+        cur = 0; off = 0; pass_bytes = 0;
+    }
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes == 0) bytes = 256;
+        pass_bytes += bytes;
         while (cur < chunks.size()) {
             if (off + bytes <= chunks[cur].cap) {
                 void* r = chunks[cur].p + off;
@@ -56,8 +74,10 @@ struct Arena {
         }
         Chunk c;
         c.cap = std::max(bytes, chunk_default);
-        if (hipMalloc((void**)&c.p, c.cap) != hipSuccess)
+        if (hipMalloc((void**)&c.p, c.cap) != hipSuccess) {
+            (void)hipGetLastError();
             throw K82Error(K82_ENOMEM, "hipMalloc of " + std::to_string(c.cap) + " bytes failed (workspace)");
+        }
         chunks.push_back(c);
         cur = chunks.size() - 1;
         off = bytes;
@@ -67,7 +87,7 @@ struct Arena {
     void release() {
         for (auto& c : chunks) (void)hipFree(c.p);
         chunks.clear();
-        reset();
+        cur = 0; off = 0; pass_bytes = 0; high = 0;
     }
 };
 
