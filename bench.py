@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -91,9 +92,17 @@ def main():
     dt = time.perf_counter() - t0
     conv_ms, conv_n, conv_flops = eng.prof_read("conv_mfma_2x2")
     fam = {}
-    for name in ("conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "source", "other"):
+    for name in ("conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "gather", "source", "other"):
         ms, n, w = eng.prof_read(name)
         fam[name] = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps}
+        if ms > 0 and w > 0:
+            if name in ("instnorm", "istft", "gather"):          # HBM-bound: algorithmic bytes / HIP-event time
+                gbs = w / (ms * 1e-3) / 1e9
+                fam[name].update({"bound": "hbm", "achieved_GBps": gbs, "frac_of_8TBps": gbs / PEAK_HBM_GBPS})
+            elif name == "conv_mfma_1x4":
+                fam[name].update({"bound": "mfma", "achieved_TFLOPs": w / (ms * 1e-3) / 1e12})
+            elif name == "lstm":                                  # latency-bound: sequential steps per second
+                fam[name].update({"bound": "latency", "sentence_steps_per_s": w / (ms * 1e-3)})
     eng.prof_enable(False)
 
     audio_s = total / spec.SAMPLE_RATE

@@ -110,8 +110,8 @@ struct ResBlock1W {
 };
 struct LNW { float* w; float* b; };
 
-enum { FAM_CONV22 = 0, FAM_CONV14, FAM_LSTM, FAM_STATS, FAM_ATTN, FAM_ISTFT, FAM_SRC, FAM_OTHER, NFAM };
-const char* const kFamNames[NFAM] = {"conv_mfma_2x2", "conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "source", "other"};
+enum { FAM_CONV22 = 0, FAM_CONV14, FAM_LSTM, FAM_STATS, FAM_ATTN, FAM_ISTFT, FAM_SRC, FAM_OTHER, FAM_GATHER, NFAM };
+const char* const kFamNames[NFAM] = {"conv_mfma_2x2", "conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "source", "other", "gather"};
 
 struct DebugT { std::vector<float> v; int64_t dims[3]; };
 
@@ -710,7 +710,10 @@ struct k82_handle {
 
         // ---- length regulation + F0/N predictor (rows a9, a10)
         float* en = aF.f((size_t)nb * 640 * PF);
-        timed(FAM_OTHER, 0, [&] { launch_gather(dcat, (long)640 * Tp_, Tp_, 640, idx, PF, nfr_d, en, (long)640 * PF, PF, nb, Fmax, st); });
+        double sumTok = 0;
+        for (int b = 0; b < nb; ++b) sumTok += lens_h[b];
+        // length regulation: algorithmic bytes = one read of the token rows + one write of the frame rows
+        timed(FAM_GATHER, 4.0 * 640 * (sumTok + sumF), [&] { launch_gather(dcat, (long)640 * Tp_, Tp_, 640, idx, PF, nfr_d, en, (long)640 * PF, PF, nb, Fmax, st); });
         tap("en", en, 640, PF, (long)640 * PF, nb);
         float* sh = aF.f((size_t)nb * H * PF);
         lstm(shared, en, (long)640 * PF, PF, 640, lF, Fmax, hb, sh, (long)H * PF, PF, aF, sumF);
@@ -748,7 +751,7 @@ struct k82_handle {
         const int C0 = ru(H + 2, 16), C1 = ru(1024 + 64 + 2, 16);
         float* cat0 = aF.f((size_t)nb * C0 * PF);
         const long c0bs = (long)C0 * PF;
-        timed(FAM_OTHER, 0, [&] { launch_gather(te2, tbs, Tp_, H, idx, PF, nfr_d, cat0, c0bs, PF, nb, Fmax, st); });
+        timed(FAM_GATHER, 4.0 * H * (sumT + sumF), [&] { launch_gather(te2, tbs, Tp_, H, idx, PF, nfr_d, cat0, c0bs, PF, nb, Fmax, st); });
         tap("asr", cat0, H, PF, c0bs, nb);
         timed(FAM_OTHER, 0, [&] { launch_conv_k3s2(f0, P2, f0conv_w, cat0 + (long)H * PF, c0bs, nfr_d, nb, Fmax, st); });
         timed(FAM_OTHER, 0, [&] { launch_conv_k3s2(nn, P2, nconv_w, cat0 + (long)(H + 1) * PF, c0bs, nfr_d, nb, Fmax, st); });

@@ -360,16 +360,31 @@ void launch_alignment(const int* dur, int Tmax, const int* lens, int B, int* idx
     hipLaunchKernelGGL(alignment_kernel, dim3(B), dim3(256), 0, s, dur, Tmax, lens, idx, ipitch, nfr);
 }
 
-__global__ void gather_kernel(const float* x, long xbs, int xpitch, const int* idx, int ipitch, const int* nfr,
-                              float* y, long ybs, int ypitch) {
-    const int b = blockIdx.z, c = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= nfr[b]) return;
-    y[(long)b * ybs + (long)c * ypitch + f] = x[(long)b * xbs + (long)c * xpitch + idx[(long)b * ipitch + f]];
+// Length regulation.  A thread owns 4 consecutive frames (one int4 of token indices, reused for GC channels)
+// and writes one float4 per channel; the token-rate rows it reads are tiny and L2-resident, so the traffic is
+// the frame-rate write.  Rows are padded to 4 floats: a float4 that starts inside the row is stored whole.
+#define GATHER_GC 8
+__global__ __launch_bounds__(256) void gather_kernel(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch,
+                                                     const int* nfr, float* y, long ybs, int ypitch) {
+    const int b = blockIdx.z, c0 = blockIdx.y * GATHER_GC, f = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int F = nfr[b];
+    if (f >= F) return;
+    const int4 i4 = *reinterpret_cast<const int4*>(idx + (long)b * ipitch + f);
+    const int i0 = i4.x, i1 = f + 1 < F ? i4.y : i0, i2 = f + 2 < F ? i4.z : i0, i3 = f + 3 < F ? i4.w : i0;
+    const float* xb = x + (long)b * xbs;
+    float* yb = y + (long)b * ybs + f;
+#pragma unroll
+    for (int k = 0; k < GATHER_GC; ++k) {
+        const int c = min(c0 + k, C - 1);            // the clamped duplicate rewrites the same values: harmless
+        const float* xr = xb + (long)c * xpitch;
+        *reinterpret_cast<float4*>(yb + (long)c * ypitch) = make_float4(xr[i0], xr[i1], xr[i2], xr[i3]);
+    }
 }
 void launch_gather(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch, const int* nfr, float* y,
                    long ybs, int ypitch, int B, int Fmax, hipStream_t s) {
-    hipLaunchKernelGGL(gather_kernel, dim3(DIVUP(Fmax, 256), C, B), dim3(256), 0, s, x, xbs, xpitch, idx, ipitch, nfr,
-                       y, ybs, ypitch);
+    // host-checked: ipitch, ypitch multiples of 4 (int4 / float4 accesses), Fmax <= ipitch
+    hipLaunchKernelGGL(gather_kernel, dim3(DIVUP(DIVUP(Fmax, 4), 256), DIVUP(C, GATHER_GC), B), dim3(256), 0, s, x, xbs,
+                       xpitch, C, idx, ipitch, nfr, y, ybs, ypitch);
 }
 
 // ------------------------------------------- depthwise ConvTranspose1d k3 s2 p1 op1 ("pool")

@@ -175,27 +175,41 @@ void launch_stft(const float* har_src, long hbs, const int* nfr, int B, int Fmax
 // HBM traffic: 22 floats read per frame (neighbour re-reads hit L1/L2) + 5 floats written.
 __global__ __launch_bounds__(256) void istft_kernel(const float* cp, long cbs, int cpitch, const int* nfr, float* audio,
                                                    const int64_t* aoff) {
+    // A block owns 256 consecutive hops; the spectra of its 259 frames (one before, two after) are turned into
+    // (re, im) ONCE into LDS -- exp, sin and sincos are the cost of this kernel, and every frame feeds four hops.
+    __shared__ float sre[11][260], sim[11][260];
     const int b = blockIdx.y;
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.x * 256;
     const int F = nfr[b];
-    if (m >= 120 * F) return;
+    if (m0 >= 120 * F) return;                      // block-uniform
     const int NF = 120 * F + 1;
     const float* c = cp + (long)b * cbs;
+    for (int f = threadIdx.x; f < 259; f += 256) {
+        const int mm = m0 - 1 + f;
+        const bool ok = mm >= 0 && mm < NF;
+        const int mc = min(max(mm, 0), NF - 1);
+#pragma unroll
+        for (int k = 0; k <= 10; ++k) {
+            const float spec = expf(c[(long)k * cpitch + mc]);
+            const float phs = sinf(c[(long)(11 + k) * cpitch + mc]);
+            float sn, cs;
+            sincosf(phs, &sn, &cs);
+            sre[k][f] = ok ? spec * cs : 0.f;
+            sim[k][f] = ok ? spec * sn : 0.f;
+        }
+    }
+    __syncthreads();
+    const int m = m0 + threadIdx.x;
+    if (m >= 120 * F) return;
     float out[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, env[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dm = -1; dm <= 2; ++dm) {
         const int mm = m + dm;
         if (mm < 0 || mm >= NF) continue;
+        const int f = threadIdx.x + dm + 1;
         float re[11], im[11];
 #pragma unroll
-        for (int k = 0; k <= 10; ++k) {
-            const float spec = expf(c[(long)k * cpitch + mm]);
-            const float phs = sinf(c[(long)(11 + k) * cpitch + mm]);
-            float sn, cs;
-            sincosf(phs, &sn, &cs);
-            re[k] = spec * cs;
-            im[k] = spec * sn;
-        }
+        for (int k = 0; k <= 10; ++k) { re[k] = sre[k][f]; im[k] = sim[k][f]; }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int j = 10 + i - 5 * dm;          // 0..19 by construction
