@@ -321,3 +321,24 @@ def test_kpipeline_front_door():
     assert out.audio.numel() == 600 * int(out.pred_dur.sum()) and len(out.pred_dur) == 8
     quiet = KPipeline(lang_code="a", model=False)
     assert [r.audio for r in quiet("Only phonemes.")] == [None]
+
+
+@pytest.mark.gpu
+def test_readaloud_on_gpu():
+    """TTSEngine over the real engine: every sentence is played once, in order; the awaited sentence is
+    synthesized alone and the rest of the look-ahead window arrives as one batched call whose audio equals
+    what single-sentence calls give (seeded noise aside: compare lengths = durations)."""
+    from tts_amd import Kokoro
+    from tts_amd.readaloud import NullSink, TTSEngine
+    k = Kokoro("synthetic", None)
+    sents = ["The quick brown fox.", "It jumps over the lazy dog!", "Again and again?", "Then it rests.", "The end."]
+    sink = NullSink()
+    e = TTSEngine(k, sink, debounce=0.05)
+    fin = []
+    e.speak_sentences_list(sents, voice="af_synthetic", finished_callback=lambda: fin.append(1))
+    assert e.wait(60.0) and fin == [1]
+    assert [i for i, _ in sink.played] == [0, 1, 2, 3, 4]
+    assert e.synth_log[0][0] == (0,) and any(len(ix) > 1 for ix, _ in e.synth_log)
+    singles = [len(k.create(t, voice="af_synthetic", trim=False)[0]) for t in sents]
+    batch = [len(a) for a, _ in k.create_batch(sents, voice="af_synthetic", trim=False)]
+    assert singles == batch and all(n % 600 == 0 and n > 0 for n in batch)

@@ -172,7 +172,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
                     else u = fmaxf(u, u * slope);
                     v[e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
                 }
-                if (col < WP) *reinterpret_cast<float4*>(dst + c * WP + col) = make_float4(v[0], v[1], v[2], v[3]);
+                // lanes past the row end write to a dump slot in the wave's (idle) epilogue patch: no branch
+                float* d = (col < WP) ? dst + c * WP + col : patch + 4 * lane;
+                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     };
@@ -217,6 +219,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
         }
     };
 
+    // (Tried and measured on one box, none kept: slicing the staging transform between the MFMA pairs of the
+    // second tap so it issues in their shadow -- 0..2 % slower; sched_group_barrier patterns for the same --
+    // ignored by the scheduler; non-temporal epilogue stores -- no change; the stores themselves cost < 5 %.)
     // ---- epilogue of one output tile.  D layout: column j = lane&31 (t), row i = (r&3) + 8*(r>>2)
     // + 4*(lane>>5) (co).  The wide epilogues send each 32x32 accumulator tile through the wave's LDS
     // patch and read it back as float4 along t: 4 dwordx4 stores of 8 rows x 128 B per tile, float4
