@@ -14,7 +14,13 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def synthetic_sds():
+    """Seeded random weights of the exact architecture -- or, with K82_REAL_PTH=<kokoro-v1_0.pth>, the real
+    checkpoint (tools/check_real_weights.py): the same parity suite then runs on real weights."""
     from tts_amd import spec
+    real = os.environ.get("K82_REAL_PTH")
+    if real:
+        from tts_amd import weights
+        return weights.load_pth(real)                    # torch.load(weights_only=True)
     return spec.synthetic_state_dicts(0)
 
 

@@ -1,60 +1,25 @@
 """Parity suite on REAL Kokoro weights, for whoever has them.  Offline there is no
 checkpoint, so the committed tests use seeded random weights of the same architecture ("parity unpinned").
-Given the hexgrad files this script re-runs the core checks against them:
+Given the hexgrad checkpoint this runs the SAME GPU parity tests (bit-exact durations, stage-wise and waveform
+parity against oracle/kokoro_ref.py, padding invisibility, ...) with those weights:
 
-    python tools/check_real_weights.py kokoro-v1_0.pth [config.json] [voices/af_heart.pt] [--n 4]
+    python tools/check_real_weights.py /path/to/kokoro-v1_0.pth
 
-and, if the `kokoro` package itself is importable, also compares with `kokoro.KModel` (the true reference).
-Needs a GPU (the engine has no CPU path).  Exit status 0 = all bars met."""
-import argparse
+The golden-fixture test is deselected (it pins the synthetic weights).  If the `kokoro` package is importable the
+script says so: comparing with `kokoro.KModel` itself is then one call on the same ids / ref_s (not automated).
+Needs a GPU (the engine has no CPU path).  Exit status = pytest's."""
 import os
+import subprocess
 import sys
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-ap = argparse.ArgumentParser()
-ap.add_argument("pth")
-ap.add_argument("config", nargs="?")
-ap.add_argument("voice", nargs="?")
-ap.add_argument("--n", type=int, default=4)
-args = ap.parse_args()
-
-import torch  # noqa: E402
-
-from oracle import kokoro_ref as R  # noqa: E402  (checker only)
-from tts_amd import spec, weights as W  # noqa: E402
-from tts_amd.engine import Engine  # noqa: E402
-
-sds = W.load_pth(args.pth)                                   # torch.load(weights_only=True)
-cfg = W.load_config(args.config) if args.config else dict(spec.DEFAULT_CONFIG)
-pack = next(iter(W.load_voices(args.voice).values())) if args.voice else spec.synthetic_voice_pack(1)
-oracle = R.build(sds, cfg)
-eng = Engine(sds, cfg)
-rng = np.random.default_rng(0)
-ok = True
-for k in range(args.n):
-    T = int(rng.integers(12, 200))
-    ids = [int(x) for x in rng.integers(1, 178, size=T)]
-    ref = np.asarray(pack, np.float32).reshape(pack.shape[0], -1)[min(T, pack.shape[0] - 1)][None]
-    padded = torch.tensor([[0] + ids + [0]], dtype=torch.long)
-    pred_e, nfr = eng.durations(*eng.pack([ids]), ref)
-    pred_o = oracle.durations(padded, torch.from_numpy(ref), 1.0)
-    same = np.array_equal(pred_e[0, :T + 2], np.asarray(pred_o).reshape(-1)[:T + 2])
-    noise = R.counter_noise(k, int(nfr[0]) * 600 * 10).reshape(1, -1)  # caller-supplied noise for both sides
-    audio_e, _ = eng.decode(noise=noise[:, :int(nfr[0]) * 600 * 9])
-    dbg = {}
-    audio_o = oracle.forward_with_tokens(padded, torch.from_numpy(ref), 1.0, noise=noise, pred_dur=torch.from_numpy(pred_e[:, :T + 2].astype(np.int64)))
-    err = float(np.abs(audio_e - np.asarray(audio_o).reshape(-1)[:len(audio_e)]).max())
-    print(f"sentence {k}: T={T} durations {'bit-exact' if same else 'DIFFER'}; free-running waveform max-abs {err:.3e} "
-          "(the <=1e-3 bar is asserted teacher-forced, see tests/test_gpu_parity.py and DESIGN.md section 6)")
-    ok &= same
-try:                                                          # the real reference, when present
-    from kokoro import KModel  # noqa: F401
-    print("kokoro package importable: compare with KModel(config, model) using the same ids/ref_s (not automated here)")
+if len(sys.argv) != 2 or not os.path.exists(sys.argv[1]):
+    sys.exit(__doc__)
+try:
+    import kokoro  # noqa: F401
+    print("[info] the kokoro package is importable here: KModel can serve as the true reference")
 except Exception:
-    print("kokoro package not importable: compared with the in-repo restatement only")
-sys.exit(0 if ok else 1)
+    print("[info] kokoro package not importable: checking against the in-repo restatement only")
+env = dict(os.environ, K82_REAL_PTH=os.path.abspath(sys.argv[1]))
+sys.exit(subprocess.call([sys.executable, "-u", "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu",
+                          "-x", "-q", "-k", "not golden", "--timeout", "300", "--timeout-method", "thread"], env=env, cwd=ROOT))
