@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 (same guide); only used with --dtype bf16
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -38,6 +39,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 (BASELINE configs[1], the default) or bf16 MFMA in the decoder/generator (cfg3's dtype)")
     args = ap.parse_args()
 
     import torch
@@ -53,7 +56,8 @@ def main():
     from tts_amd.engine import Engine
 
     sds = spec.synthetic_state_dicts(0)
-    eng = Engine(sds, device=local)
+    eng = Engine(sds, device=local, precision=args.dtype)
+    bf16 = args.dtype == "bf16"
     B, T = args.batch, args.tokens
     rng = np.random.default_rng(1000 + rank)                 # each rank synthesizes different sentences
     ids = np.zeros((B, T), dtype=np.int64)
@@ -121,7 +125,7 @@ def main():
         # same command (counters cannot be read from inside the process); see profiles/*_traffic.json.
         traffic, traffic_src = None, None
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v2_traffic.json")
-        if os.path.exists(tp) and B == 64 and T == 256:
+        if os.path.exists(tp) and B == 64 and T == 256 and not bf16:
             with open(tp) as fh:
                 traffic = json.load(fh)["conv_mfma_2x2_family"]["traffic_bytes_per_launch_corrected"]
             traffic_src = "profiles/r01_v2_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes"
@@ -136,9 +140,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 (decoder/generator MFMA operands; fp32 accumulate, activations, durations, F0)" if bf16 else "f32",
             "data": "synthetic phoneme ids, seeded random weights of the Kokoro-82M architecture, synthetic voice pack",
-            "config": {"workload": "configs[1]: Kokoro-82M fp32, 64 phoneme sequences x 256 tokens per GPU, "
+            "config": {"workload": ("configs[1] shape in bf16 mode" if bf16 else "configs[1]") + ": Kokoro-82M, 64 phoneme sequences x 256 tokens per GPU, "
                                    "durations predicted by the model", "batch_per_gpu": B, "tokens": T,
                        "frames_per_gpu": int(nfr.sum()), "audio_s_per_step_per_gpu": audio_s,
                        "parallelism": f"dp{world} (sentence sharding, no data-path collective)",
@@ -147,9 +151,10 @@ def main():
                 "kernel": "conv_mfma_kernel<2,2> (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "peak": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS))
+                        if conv_ms > 0 else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "launches_per_step": conv_n / args.steps,

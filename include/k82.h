@@ -111,6 +111,14 @@ int k82_synthesize(k82_handle* h, const int64_t* ids, const int32_t* lens, int B
                    int32_t* pred_dur, float* audio, int64_t capacity, int64_t* audio_off,
                    void* stream);
 
+/* Compute precision of the frame-rate convolutions (decoder + generator; SURVEY.md 8d cfg3 "bf16 decoder").
+ *   mode 0 (default): every convolution on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
+ *   mode 1: the decoder / generator convolutions round weights and staged activations to bf16 and use
+ *           v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations stay fp32 in HBM; durations, the F0/N
+ *           curves, the harmonic source, conv_post and the iSTFT stay fp32 (durations remain bit-exact).
+ * No counterpart in the reference (onnxruntime runs the fp32 graph); north_star's bf16 bar is SNR >= 40 dB. */
+int k82_set_precision(k82_handle* h, int mode);
+
 /* float -> 16-bit PCM as the reference callers do: clip(x,-1,1)*32767 -> '<i2'
  * (basic.tts_kokoro_2_play_pause_works.py:25).  src/dst host or device. */
 int k82_pcm16(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* stream);

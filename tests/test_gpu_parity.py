@@ -342,3 +342,63 @@ def test_readaloud_on_gpu():
     singles = [len(k.create(t, voice="af_synthetic", trim=False)[0]) for t in sents]
     batch = [len(a) for a, _ in k.create_batch(sents, voice="af_synthetic", trim=False)]
     assert singles == batch and all(n % 600 == 0 and n > 0 for n in batch)
+
+
+@pytest.mark.gpu
+def test_bf16_conv_op_matches_fp32_reference(engine):
+    """bf16 MFMA mode of the conv kernel (k82_set_precision 1) against torch fp32 conv1d: operands are rounded to
+    bf16 (2^-9 relative each), accumulation is fp32, so the error of a K-term dot product is ~2^-8 * |x||w| /
+    sqrt(K) of the output scale: bound 2e-2 of max|ref|, and the fp32 mode must be restored afterwards."""
+    import torch
+    rng = np.random.default_rng(5)
+    engine.set_precision("bf16")
+    try:
+        for (cin, cout, L, B, k, dil, act) in [(128, 128, 700, 2, 7, 3, 2), (256, 256, 333, 3, 3, 1, 1), (1090, 1024, 97, 2, 3, 1, 0),
+                                               (130, 256, 260, 1, 11, 5, 2)]:
+            x = rng.standard_normal((B, cin, L)).astype(np.float32)
+            w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+            b = rng.standard_normal(cout).astype(np.float32)
+            alpha = (1 + 0.5 * rng.random(cin)).astype(np.float32)
+            y, _ = engine.op_conv1d(x, w, b, dil=dil, act=act, slope=0.2, alpha=alpha if act == 2 else None)
+            xt = torch.from_numpy(x)
+            if act == 1:
+                xt = torch.nn.functional.leaky_relu(xt, 0.2)
+            elif act == 2:
+                a = torch.from_numpy(alpha)[None, :, None]
+                xt = xt + torch.sin(a * xt) ** 2 / a
+            ref = torch.nn.functional.conv1d(xt, torch.from_numpy(w), torch.from_numpy(b), padding=dil * (k - 1) // 2,
+                                             dilation=dil).numpy()
+            err = float(np.abs(y - ref).max()) / float(np.abs(ref).max())
+            print(f"bf16 conv cin={cin} cout={cout} k={k}: rel err {err:.2e}")
+            assert 1e-5 < err < 2e-2                              # really bf16 (not silently fp32), and close
+    finally:
+        engine.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_bf16_decoder_mode_snr(engine):
+    """north_star: bf16 waveform SNR >= 40 dB.  Same batch, same noise, fp32 vs bf16 decoder/generator convs:
+    durations and the F0/N curves (computed before the switch) must be IDENTICAL, so the harmonic source is the
+    same signal in both runs and the SNR measures the bf16 rounding of the decoder + generator only."""
+    id_lists, ref_s = H.make_batch(11, [23, 77, 150])
+    ids, lens = engine.pack(id_lists)
+    engine.debug_enable(True)
+    try:
+        pred32, nfr = engine.durations(ids, lens, ref_s)
+        noise = _noise_for(nfr)
+        a32, off = engine.decode(noise=noise)
+        f0_32 = engine.debug_get("F0").copy()
+        engine.set_precision("bf16")
+        pred16, nfr16 = engine.durations(ids, lens, ref_s)
+        a16, off16 = engine.decode(noise=noise)
+        f0_16 = engine.debug_get("F0").copy()
+    finally:
+        engine.set_precision("fp32")
+        engine.debug_enable(False)
+    assert np.array_equal(pred32, pred16) and np.array_equal(off, off16) and np.array_equal(f0_32, f0_16)
+    assert not np.array_equal(a32, a16)                           # the mode really changed the arithmetic
+    for b in range(len(id_lists)):
+        s, e = off[b], off[b + 1]
+        snr = 10 * np.log10(float(np.sum(a32[s:e].astype(np.float64) ** 2)) / float(np.sum((a32[s:e] - a16[s:e]).astype(np.float64) ** 2)))
+        print(f"sentence {b}: bf16 vs fp32 SNR {snr:.1f} dB")
+        assert snr >= 40.0

@@ -26,6 +26,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--max-sentences", type=int, default=0)
 ap.add_argument("--latency-sentences", type=int, default=200)
 ap.add_argument("--max-batch", type=int, default=256)
+ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32")
 args = ap.parse_args()
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -40,7 +41,7 @@ ids = [x for x in ids if x]
 pack = spec.synthetic_voice_pack(1)
 rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
 
-eng = Engine(spec.synthetic_state_dicts(0))
+eng = Engine(spec.synthetic_state_dicts(0), precision=args.dtype)
 syn = BatchSynthesizer(eng, max_batch=args.max_batch)
 syn.synthesize(ids[:64], rows[:64])                        # warm-up (arena growth, first launches)
 t0 = time.perf_counter()
@@ -48,7 +49,7 @@ res = syn.synthesize(ids, rows)
 dt = time.perf_counter() - t0
 a = audio_seconds([res[i][0] for i in range(len(ids))])
 tok = sum(len(x) + 2 for x in ids)
-print(json.dumps({"config": "cfg3 (1 GPU, fp32): The Art of War, every sentence", "sentences": len(ids), "tokens": tok,
+print(json.dumps({"config": f"cfg3 (1 GPU, {args.dtype}): The Art of War, every sentence", "sentences": len(ids), "tokens": tok,
                   "mean_tokens": tok / len(ids), "audio_s": a, "wall_s": dt, "audio_s_per_s": a / dt,
                   "phonemes": "surrogate g2p (no phonemizer offline)", "weights": "seeded random",
                   "includes": "host packing, H2D ids, D2H audio copies per batch"}), flush=True)
@@ -67,7 +68,7 @@ for k, i in enumerate(pick):
     lat.append((time.perf_counter() - t0) * 1e3)
     aud.append(len(audios[0]) / 24000.0)
 lat = np.array(lat[5:])                                    # first calls grow the arena
-print(json.dumps({"config": "cfg5 (B=1): sentence lengths of Sound-of-Sirens, one at a time", "sentences": len(lat),
+print(json.dumps({"config": f"cfg5 (B=1, {args.dtype}): sentence lengths of Sound-of-Sirens, one at a time", "sentences": len(lat),
                   "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
                   "mean_ms": float(lat.mean()), "mean_audio_s": float(np.mean(aud[5:])),
                   "realtime_factor_p50": float(np.mean(aud[5:]) / (np.percentile(lat, 50) / 1e3))}), flush=True)

@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 from tts_amd import spec  # noqa: E402
 from tts_amd.engine import Engine  # noqa: E402
 
-eng = Engine(spec.synthetic_state_dicts(0))
+eng = Engine(spec.synthetic_state_dicts(0), precision=os.environ.get("K82_PRECISION", "fp32"))
+print("precision", eng.precision)
 rng = np.random.default_rng(0)
 shapes = [  # (cin, cout, L, B, taps, dil)
     (128, 128, 92161, 8, 3, 1), (128, 128, 92161, 8, 7, 1), (128, 128, 92161, 8, 7, 3), (128, 128, 92161, 8, 11, 5),

@@ -24,6 +24,7 @@
 #include "kernels.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float gelu_new(float x) {
     const float k = 0.7978845608028654f;   // sqrt(2/pi)
@@ -57,7 +58,12 @@ __device__ __forceinline__ float snake(float v, float al, float ial) {
 //   EPI_SCALAR transposed-conv phase interleave (up_s) / x2 nearest residual (res_shift): dword path
 enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3 };
 
-template <int WM, int WN, int EPI, bool SNAKE>
+// BF16 = true: same staging, same epilogues, but the MFMAs are v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
+// the A operand is the pre-packed bf16 weight image (one 16-byte load per lane, row and k-half), the B operand
+// is read from the fp32 LDS tile (8 ds_read_b32 down the channel axis) and rounded to bf16 in registers
+// (v_cvt_pk_bf16_f32, round-to-nearest-even).  One MFMA covers the whole 16-channel tile of a tap, so the
+// matrix pipe needs 1/16 of the fp32 time and the kernel becomes a streaming (HBM / staging bound) kernel.
+template <int WM, int WN, int EPI, bool SNAKE, bool BF16>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN, KC = 16, WP = BN + 68, NW = WM * WN;
     constexpr int CPW = KC / NW;               // channels staged per wave
@@ -179,13 +185,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
         }
     };
 
-    float a0[KC / 2][2], a1[KC / 2][2];     // A fragments of the tap being consumed / the next one
+    // A fragments of the tap being consumed / the next one.  fp32: [kk][mi] scalars; bf16: element [j][mi] is
+    // dword j of the lane's 16-byte (8 x bf16) fragment, j < 4
+    float a0[KC / 2][2], a1[KC / 2][2];
     auto load_a = [&](int m0, int ci0, int tap, float (&a)[KC / 2][2]) {
-        const float* wp = p.w + ((long)(tap * p.cin_p + ci0 + lhi) * p.cout_p) + m0 + l31;
+        if constexpr (BF16) {
+            const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
+                              ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31);
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            a[kk][0] = wp[(long)(2 * kk) * p.cout_p];
-            a[kk][1] = wp[(long)(2 * kk) * p.cout_p + 32];
+            for (int mi = 0; mi < 2; ++mi) {
+                const uint4 u = wp[32 * mi];
+                a[0][mi] = __uint_as_float(u.x); a[1][mi] = __uint_as_float(u.y);
+                a[2][mi] = __uint_as_float(u.z); a[3][mi] = __uint_as_float(u.w);
+            }
+        } else {
+            const float* wp = p.w + ((long)(tap * p.cin_p + ci0 + lhi) * p.cout_p) + m0 + l31;
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                a[kk][0] = wp[(long)(2 * kk) * p.cout_p];
+                a[kk][1] = wp[(long)(2 * kk) * p.cout_p + 32];
+            }
         }
     };
     // a0 <- a1 through opaque moves.  With plain copies hipcc coalesces a1 into a0 across the loop; with a0
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     // the step, ~2000 cycles after the loads were issued.
     auto rotate_a = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
+        for (int kk = 0; kk < (BF16 ? 4 : KC / 2); ++kk) {
             asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][0]) : "v"(a1[kk][0]));
             asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][1]) : "v"(a1[kk][1]));
         }
@@ -203,19 +222,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
     // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
     auto mfma_tap = [&](const float* xsb, int off, const float (&a)[KC / 2][2]) {
-        const float* xsp = xsb + lhi * WP + nw + l31 + off;
-        float b[KC / 2][2];
+        if constexpr (BF16) {
+            const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;      // lane: channels 8*lhi .. +7, column l31
+            union { bf16x8 v; unsigned u[4]; } am[2], bm;
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            b[kk][0] = xsp[2 * kk * WP];
-            b[kk][1] = xsp[2 * kk * WP + 32];
-        }
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b[kk][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b[kk][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b[kk][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b[kk][1], acc[1][1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) am[mi].u[j] = __float_as_uint(a[j][mi]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bm.v[j] = (__bf16)xsp[j * WP + 32 * ni];
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0].v, bm.v, acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1].v, bm.v, acc[1][ni], 0, 0, 0);
+            }
+        } else {
+            const float* xsp = xsb + lhi * WP + nw + l31 + off;
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                const float b0 = xsp[2 * kk * WP];
+                const float b1 = xsp[2 * kk * WP + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b1, acc[1][1], 0, 0, 0);
+            }
         }
     };
 
@@ -392,19 +423,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
     }
 }
 
-template <int WM, int WN, bool SNAKE>
+template <int WM, int WN, bool SNAKE, bool BF16>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     switch (epi) {
-    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_PLAIN, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_RES, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_ACC, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
-    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_SCALAR, SNAKE>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_PLAIN, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_RES, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_ACC, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_SCALAR, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
     }
 }
 template <int WM, int WN>
 static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
-    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true>(p, epi, grid, s);
-    else launch_epi<WM, WN, false>(p, epi, grid, s);
+    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, false>(p, epi, grid, s);
+    else launch_epi<WM, WN, false, false>(p, epi, grid, s);
+}
+static void launch_bf16(const ConvP& p, int epi, unsigned grid, hipStream_t s) {       // 2x2 shape only
+    if (p.act == ACT_SNAKE) launch_epi<2, 2, true, true>(p, epi, grid, s);
+    else launch_epi<2, 2, false, true>(p, epi, grid, s);
 }
 
 // Persistent launch: at most CUS x BLOCKS_PER_CU workgroups walk the output tiles.
@@ -416,7 +451,9 @@ void launch_conv(const ConvP& p, hipStream_t s) {
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
-        launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
+        const unsigned grid = (unsigned)(total < kMaxBlocks ? total : kMaxBlocks);
+        if (p.wb) launch_bf16(p, epi, grid, s);
+        else launch_shape<2, 2>(p, epi, grid, s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
         launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);

@@ -95,6 +95,7 @@ struct HostT { std::vector<float> v; std::vector<int64_t> shape; };
 
 struct ConvW {
     float* w = nullptr; float* bias = nullptr;
+    uint16_t* wb = nullptr;            // bf16 image for the bf16 MFMA mode (2x2 tile shape only)
     int cin = 0, cin_p = 0, cout = 0, cout_p = 0, taps = 0, pad = 0;
     unsigned* tapmask = nullptr; int up_s = 0, up_shift = 0;
 };
@@ -144,6 +145,8 @@ struct k82_handle {
     // ---- workspace + phase-1 state
     Arena aT, aF;
     bool have_phase1 = false;
+    int precision = 0;                 // k82_set_precision: 0 fp32 everywhere, 1 bf16 MFMA in decoder + generator
+    bool bf16_now = false;             // true only while decode() is inside the decoder / generator
     size_t aT_mark_cur = 0, aT_mark_off = 0;
     int B = 0, Tmax = 0, Tp = 0;
     std::vector<int> lens_h, dur_h;
@@ -169,6 +172,29 @@ struct k82_handle {
     float* upload(const std::vector<float>& v) {
         float* d = (float*)wmalloc(v.size() * sizeof(float));
         HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return d;
+    }
+    // bf16 (round-to-nearest-even) image of a device-layout weight tensor t[tap][cin_p][cout_p]:
+    // [tap][cin_p/16][k-half][cout_p][8] -- the 16 bytes a lane of v_mfma_f32_32x32x16_bf16 needs, contiguous
+    static uint16_t bf16_rne(float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);     // NaN stays NaN
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    uint16_t* upload_bf16(const std::vector<float>& t, int taps, int cin_p, int cout_p) {
+        if (cout_p % 128 != 0) return nullptr;
+        const int nt = cin_p / 16;
+        std::vector<uint16_t> o((size_t)taps * cin_p * cout_p);
+        for (int kk = 0; kk < taps; ++kk)
+            for (int it = 0; it < nt; ++it)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int co = 0; co < cout_p; ++co)
+                        for (int j = 0; j < 8; ++j)
+                            o[((((size_t)kk * nt + it) * 2 + hh) * cout_p + co) * 8 + j] =
+                                bf16_rne(t[((size_t)kk * cin_p + it * 16 + 8 * hh + j) * cout_p + co]);
+        uint16_t* d = (uint16_t*)wmalloc(o.size() * sizeof(uint16_t));
+        HIPCHK(hipMemcpy(d, o.data(), o.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         return d;
     }
     const HostT& get(const std::string& name, std::initializer_list<int64_t> shape) {
@@ -234,6 +260,7 @@ struct k82_handle {
                 for (int kk = 0; kk < k; ++kk)
                     t[((size_t)kk * c.cin_p + ci) * c.cout_p + co] = W[((size_t)co * cin + ci) * k + kk];
         c.w = upload(t);
+        c.wb = upload_bf16(t, k, c.cin_p, c.cout_p);
         std::vector<float> bp(c.cout_p, 0.f);        // always present, padded to cout_p (the kernel loads it unconditionally)
         if (bias) std::copy(bias->begin(), bias->end(), bp.begin());
         c.bias = upload(bp);
@@ -271,6 +298,7 @@ struct k82_handle {
         for (int r = 0; r < s; ++r)
             for (int co = 0; co < cout; ++co) bp[r * cout + co] = bv.v[co];
         c.w = upload(t);
+        c.wb = upload_bf16(t, 3, c.cin_p, c.cout_p);
         c.bias = upload(bp);
         std::vector<unsigned> mask(c.cout_p / 64, 0x7u);
         for (size_t mt = 0; mt < mask.size(); ++mt) {
@@ -454,6 +482,7 @@ struct k82_handle {
         std::memset(&p, 0, sizeof(p));
         p.x = x; p.xbs = xbs; p.xpitch = xpitch;
         p.w = w.w; p.bias = w.bias;
+        p.wb = bf16_now ? w.wb : nullptr;
         p.y = y; p.ybs = ybs; p.ypitch = ypitch;
         p.lin = lin; p.lout = lout;
         p.cin = w.cin; p.cin_p = w.cin_p; p.cout = w.cout; p.cout_p = w.cout_p; p.taps = w.taps;
@@ -758,6 +787,11 @@ struct k82_handle {
         float* catA = aF.f((size_t)nb * C1 * PF);
         float* catB = aF.f((size_t)nb * C1 * PF);
         const long c1bs = (long)C1 * PF;
+        // bf16 MFMA mode (k82_set_precision): from here on -- decoder and generator convs -- the 2x2-shaped
+        // convs take their bf16 weight image; everything before (durations, F0/N curves, text encoder) and
+        // conv_post (1x4 shape) stay on the exact-fp32 instruction.  The guard clears the flag on any exit.
+        struct Bf16Scope { bool& f; ~Bf16Scope() { f = false; } } bf16_scope{bf16_now};
+        bf16_now = precision == 1;
         resblk1d(enc, cat0, c0bs, PF, lF, Fmax, hb, sumF, catA, c1bs, PF, gbd, Gd, aF);
         tap("dec_encode", catA, 1024, PF, c1bs, nb);
         for (float* cat : {catA, catB}) {
@@ -1021,6 +1055,13 @@ int k82_debug_copy(k82_handle* h, const char* name, float* dst) {
     });
 }
 
+int k82_set_precision(k82_handle* h, int mode) {
+    return guarded(h, nullptr, [&] {
+        REQUIRE(mode == 0 || mode == 1, K82_EINVAL, "precision mode must be 0 (fp32) or 1 (bf16 decoder/generator MFMA)");
+        h->precision = mode;
+    });
+}
+
 int k82_op_conv1d(k82_handle* h, const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout,
                   int L, int taps, int dil, int act, float slope, const float* alpha, int iters, float* ms) {
     return guarded(h, nullptr, [&] {
@@ -1053,6 +1094,7 @@ int k82_op_conv1d(k82_handle* h, const float* x, const float* w, const float* bi
         const LenSpec ls{nullptr, 0, L};
         ConvP p = h->cp(cw, xd, (long)cw.cin_p * P, P, yd, (long)cout * P, P, ls, ls, B, L, dil);
         p.act = act; p.slope = slope; p.alpha = ad; p.inv_alpha = iad;
+        p.wb = h->precision == 1 ? cw.wb : nullptr;          // the op hook follows k82_set_precision directly
         k82_handle::check_conv(p);
         launch_conv(p, h->st);
         if (iters > 1 || ms) {

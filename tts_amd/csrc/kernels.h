@@ -24,6 +24,8 @@ enum { OACT_NONE = 0, OACT_GELU_NEW = 1 };
 struct ConvP {
     const float* x; long xbs; int xpitch;      // input  [B][cin_p][xpitch]
     const float* w;                            // weights [taps][cin_p][cout_p] (tap-major, cout contiguous)
+    const uint16_t* wb;                        // bf16 image of the same weights (nullptr: fp32 MFMA):
+                                               // [taps][cin_p/16][2 k-halves][cout_p][8], 16 B per (row, k-half)
     const float* bias;                         // [cout_p] or nullptr
     float* y; long ybs; int ypitch;            // output (nullptr: accumulate only)
     LenSpec lin, lout;                         // input / output valid lengths
@@ -42,7 +44,7 @@ struct ConvP {
     int up_s, up_cout_shift, up_off;
     const unsigned* tapmask;                   // per 64-row M tile: bitmask of non-zero taps (nullptr: all)
     int B, Lmax_out;                           // grid extents
-    int dbg;                                   // timing experiments only (K82_CONV_DBG): 1 no stores, 2 no x restage, 4 A from one address
+    int dbg;                                   // unused (kept for ABI stability of the test hook)
 };
 void launch_conv(const ConvP& p, hipStream_t s);
 double conv_flops(const ConvP& p, const int* host_lens);   // algorithmic FLOPs of one launch

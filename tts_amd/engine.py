@@ -36,7 +36,7 @@ def _ptr(a):
 class Engine:
     """Kokoro-82M on one MI355X.  ``state_dicts``: the 5 raw checkpoint state dicts."""
 
-    def __init__(self, state_dicts, config=None, device=0):
+    def __init__(self, state_dicts, config=None, device=0, precision="fp32"):
         self.lib = _lib.load()
         self.config = config or spec.DEFAULT_CONFIG
         self.device = device
@@ -51,6 +51,13 @@ class Engine:
             shape = (C.c_int64 * arr.ndim)(*arr.shape)
             self._check(self.lib.k82_set_tensor(self.h, name.encode(), _ptr(arr), shape, arr.ndim))
         self._check(self.lib.k82_finalize(self.h))
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """"fp32" (default) or "bf16": bf16 MFMA for the decoder / generator convolutions (k82_set_precision)."""
+        mode = {"fp32": 0, "f32": 0, "bf16": 1}[precision]
+        self._check(self.lib.k82_set_precision(self.h, mode))
+        self.precision = "bf16" if mode else "fp32"
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
