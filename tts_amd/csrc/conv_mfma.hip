@@ -23,6 +23,10 @@
 // A wave owns a 64(co) x 64(t) tile = 2x2 MFMA tiles = 64 accumulator VGPRs; WM x WN waves per block.
 #include "kernels.h"
 
+#ifndef K82_OCC_BF16
+#define K82_OCC_BF16 3              // workgroups per CU (= waves per SIMD) the bf16-mode kernels are built for
+#endif
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -63,8 +67,16 @@ enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3 };
 // is read from the fp32 LDS tile (8 ds_read_b32 down the channel axis) and rounded to bf16 in registers
 // (v_cvt_pk_bf16_f32, round-to-nearest-even).  One MFMA covers the whole 16-channel tile of a tap, so the
 // matrix pipe needs 1/16 of the fp32 time and the kernel becomes a streaming (HBM / staging bound) kernel.
+// bf16 mode only: sin through the hardware v_sin_f32 (argument in revolutions, ~1e-6 absolute error for the
+// |alpha v| < 256 * 2 pi this model produces): 4 instructions instead of 14 -- in bf16 mode the staging VALU, not
+// the matrix pipe, is what the Snake convolutions wait for.
+__device__ __forceinline__ float snake_fast(float v, float al, float ial) {
+    const float sn = __builtin_amdgcn_sinf(al * v * 0.15915494309189535f);
+    return fmaf(ial, sn * sn, v);
+}
+
 template <int WM, int WN, int EPI, bool SNAKE, bool BF16>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mfma_kernel(ConvP p) {
     constexpr int BM = 64 * WM, BN = 64 * WN, KC = 16, WP = BN + 68, NW = WM * WN;
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float u = fmaf(v[e], sc, of);
-                    if constexpr (SNAKE) u = snake(u, alr[cc], ialr[cc]);
+                    if constexpr (SNAKE) u = BF16 ? snake_fast(u, alr[cc], ialr[cc]) : snake(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
                     else u = fmaxf(u, u * slope);
                     v[e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
                 }
@@ -451,7 +463,8 @@ void launch_conv(const ConvP& p, hipStream_t s) {
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
-        const unsigned grid = (unsigned)(total < kMaxBlocks ? total : kMaxBlocks);
+        const long cap = p.wb ? 256 * K82_OCC_BF16 : kMaxBlocks;
+        const unsigned grid = (unsigned)(total < cap ? total : cap);
         if (p.wb) launch_bf16(p, epi, grid, s);
         else launch_shape<2, 2>(p, epi, grid, s);
     } else {
