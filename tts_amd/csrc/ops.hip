@@ -240,25 +240,40 @@ void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long c
 // step), c stays in a register.  fp32 throughout: the duration branch must round exactly.
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void lstm_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
-                                                  long ybs, int ypitch, LenSpec ls) {
+// 1024 threads: thread (part p = tid >> 8, unit j = tid & 255) owns the k-quarter [64p, 64p + 64) of unit j's four
+// gate rows, so four times as many W_hh loads are in flight per step as with one thread per unit (the step is
+// bound by the latency of streaming 1 MB from L2 through one CU, not by its 256 k MACs); the partial sums meet
+// in LDS.  The four gate pre-activations of the NEXT step are prefetched while this step's weights stream.
+__global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
+                                                   long ybs, int ypitch, LenSpec ls) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][256];
-    const int dir = blockIdx.x, b = blockIdx.y, j = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float4 part[4][256];
+    const int dir = blockIdx.x, b = blockIdx.y, j = threadIdx.x & 255, pt = threadIdx.x >> 8;
     const int T = ls.len(b);
-    const float4* W = reinterpret_cast<const float4*>(whh) + (long)dir * 256 * 256 + j;
+    const float4* W = reinterpret_cast<const float4*>(whh) + (long)dir * 256 * 256 + (long)(64 * pt) * 256 + j;
     const float* g0 = gx + (long)b * gbs + (long)(dir * 1024 + j) * gpitch;
     const long gs = (long)256 * gpitch;
     float* yo = y + (long)b * ybs + (long)(dir * 256 + j) * ypitch;
     float c = 0.f;
-    hbuf[0][j] = 0.f;
+    if (pt == 0) hbuf[0][j] = 0.f;
+    float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pt == 0 && T > 0) {
+        const int t0 = dir ? T - 1 : 0;
+        gn = make_float4(g0[t0], g0[gs + t0], g0[2 * gs + t0], g0[3 * gs + t0]);
+    }
     __syncthreads();
     int p = 0;
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s;
-        float ai = g0[t], af = g0[gs + t], ag = g0[2 * gs + t], ao = g0[3 * gs + t];
-        const float4* h4 = reinterpret_cast<const float4*>(hbuf[p]);
-#pragma unroll 4
-        for (int k4 = 0; k4 < 64; ++k4) {
+        const float4 gcur = gn;
+        if (pt == 0 && s + 1 < T) {                                  // next step's input projection, in flight early
+            const int tn = dir ? t - 1 : t + 1;
+            gn = make_float4(g0[tn], g0[gs + tn], g0[2 * gs + tn], g0[3 * gs + tn]);
+        }
+        float ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f;
+        const float4* h4 = reinterpret_cast<const float4*>(hbuf[p]) + 16 * pt;
+#pragma unroll 8
+        for (int k4 = 0; k4 < 16; ++k4) {
             const float4 hv = h4[k4];
             const float4 w0 = W[(long)(4 * k4 + 0) * 256];
             const float4 w1 = W[(long)(4 * k4 + 1) * 256];
@@ -269,18 +284,27 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* gx, long gbs, in
             ai += w2.x * hv.z; af += w2.y * hv.z; ag += w2.z * hv.z; ao += w2.w * hv.z;
             ai += w3.x * hv.w; af += w3.y * hv.w; ag += w3.z * hv.w; ao += w3.w * hv.w;
         }
-        const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanhf(ag), og = sigmoidf_(ao);
-        c = fg * c + ig * gg;
-        const float hn = og * tanhf(c);
-        hbuf[p ^ 1][j] = hn;
-        yo[t] = hn;
+        part[pt][j] = make_float4(ai, af, ag, ao);
+        __syncthreads();
+        if (pt == 0) {
+            const float4 p0 = part[0][j], p1 = part[1][j], p2 = part[2][j], p3 = part[3][j];
+            ai = gcur.x + ((p0.x + p1.x) + (p2.x + p3.x));
+            af = gcur.y + ((p0.y + p1.y) + (p2.y + p3.y));
+            ag = gcur.z + ((p0.z + p1.z) + (p2.z + p3.z));
+            ao = gcur.w + ((p0.w + p1.w) + (p2.w + p3.w));
+            const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanhf(ag), og = sigmoidf_(ao);
+            c = fg * c + ig * gg;
+            const float hn = og * tanhf(c);
+            hbuf[p ^ 1][j] = hn;
+            yo[t] = hn;
+        }
         __syncthreads();
         p ^= 1;
     }
 }
 void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
                  int B, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(256), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
+    hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(1024), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
 }
 
 // ------------------------------------------------------------------------ small helpers
