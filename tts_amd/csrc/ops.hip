@@ -85,12 +85,72 @@ void launch_style_fc(const float* W, const float* bias, int rows, const float* r
 }
 
 // ------------------------------------------------------------- LayerNorm over channels
-// Thread per (b, t): the C channel values of one position are a strided column, adjacent
-// threads read adjacent t => coalesced.  Two-pass (mean, then centred variance).
-__global__ __launch_bounds__(64) void layernorm_cols_kernel(const float* x, const float* res, float* y, long bs,
-                                                           long ybs, int pitch, LenSpec ls, int C, float eps, const float* w,
-                                                           const float* bias, const float* gb, int gbstride,
-                                                           int goff, float leaky) {
+// Workgroup = 64 positions (lane = t, coalesced) x 16 channel groups (wave w owns channels w, w+16, ...): every
+// value is loaded ONCE into registers (up to 48 per thread, all loads independent), the 16 partial sums meet in
+// LDS.  Two-pass (mean, then centred variance) like the reference's layer_norm.  C <= 768 (checked by the launcher,
+// which falls back to the serial kernel below for anything larger).
+#define LN_MAXCH 48
+__global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, const float* res, float* y, long bs,
+                                                             long ybs, int pitch, LenSpec ls, int C, float eps, const float* w,
+                                                             const float* bias, const float* gb, int gbstride,
+                                                             int goff, float leaky) {
+    __shared__ float red[2][16][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = ls.len(b);
+    const int t = blockIdx.x * 64 + lane;
+    const bool ok = t < L;
+    const int tc = ok ? t : 0;                               // clamped: every lane loads, only valid lanes store
+    const float* xc = x + (long)b * bs + tc;
+    const float* rc = res ? res + (long)b * bs + tc : xc;
+    const float rmul = res ? 1.f : 0.f;
+    float v[LN_MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c = wv + 16 * i;
+        const int cc = c < C ? c : 0;
+        const float u = xc[(long)cc * pitch] + rmul * rc[(long)cc * pitch];
+        v[i] = c < C ? u : 0.f;
+        s += v[i];
+    }
+    red[0][wv][lane] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[0][k][lane];
+    const float mean = tot / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const float d = (wv + 16 * i < C) ? v[i] - mean : 0.f;
+        v[i] = d;
+        q += d * d;
+    }
+    red[1][wv][lane] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) qt += red[1][k][lane];
+    const float rstd = 1.0f / sqrtf(qt / C + eps);
+    float* yc = y + (long)b * ybs + tc;
+    const float* g = gb ? gb + (long)b * gbstride + goff : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c = wv + 16 * i;
+        if (c < C) {                                         // wave-uniform
+            float o = v[i] * rstd;
+            if (g) o = (1.0f + g[c]) * o + g[C + c];
+            else o = o * w[c] + bias[c];
+            if (leaky != 1.0f) o = o < 0.f ? o * leaky : o;
+            if (ok) yc[(long)c * pitch] = o;
+        }
+    }
+}
+// serial fallback (C > 768): thread per (b, t), three passes
+__global__ __launch_bounds__(64) void layernorm_cols_serial_kernel(const float* x, const float* res, float* y, long bs,
+                                                                  long ybs, int pitch, LenSpec ls, int C, float eps,
+                                                                  const float* w, const float* bias, const float* gb,
+                                                                  int gbstride, int goff, float leaky) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
     if (t >= ls.len(b)) return;
     const float* xc = x + (long)b * bs + t;
@@ -117,8 +177,12 @@ __global__ __launch_bounds__(64) void layernorm_cols_kernel(const float* x, cons
 void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, long ybs, int pitch, LenSpec ls, int C,
                            int B, int Tmax, float eps, const float* w, const float* bias, const float* gb,
                            int gbstride, int goff, float leaky, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_cols_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, x, res, y, bs, ybs, pitch, ls, C,
-                       eps, w, bias, gb, gbstride, goff, leaky);
+    if (C <= 16 * LN_MAXCH)
+        hipLaunchKernelGGL(layernorm_cols_kernel, dim3(DIVUP(Tmax, 64), B), dim3(1024), 0, s, x, res, y, bs, ybs, pitch, ls,
+                           C, eps, w, bias, gb, gbstride, goff, leaky);
+    else
+        hipLaunchKernelGGL(layernorm_cols_serial_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, x, res, y, bs, ybs, pitch,
+                           ls, C, eps, w, bias, gb, gbstride, goff, leaky);
 }
 
 // ------------------------------------------------------------------------- embeddings
