@@ -61,6 +61,9 @@ def make_batches(indices, token_counts, max_batch: int = 64, max_tokens: int = 6
         cur_max = new_max
     if cur:
         batches.append(cur)
+    # heaviest batch first: the engine's workspace arenas are sized by the largest pass seen, so they are
+    # grown once instead of once per bucket (each regrowth is a device-wide sync plus tens of GB of hipMalloc)
+    batches.sort(key=lambda bt: -sum(estimate_cost(token_counts[i]) for i in bt))
     return batches
 
 
@@ -82,7 +85,7 @@ class BatchSynthesizer:
             return
         audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
         for k, w in enumerate(where):
-            out[w] = (audio[off[k]:off[k + 1]].copy(), pred[k, :lens[k]].copy())
+            out[w] = (audio[off[k]:off[k + 1]], pred[k, :lens[k]].copy())     # views of the batch buffer: no second copy
 
     def synthesize(self, id_lists, ref_rows, speeds=None, seeds=None, indices=None):
         """-> {index: (audio f32[600 F], pred_dur i32[T])} for ``indices`` (default: all)."""
