@@ -164,7 +164,7 @@ def main():
             },
             "other_kernels": fam,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(sds, ids, ref_s, T)
         print(json.dumps(out), flush=True)
     eng.close()
