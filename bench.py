@@ -39,8 +39,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
-                    help="fp32 (BASELINE configs[1], the default) or bf16 MFMA in the decoder/generator (cfg3's dtype)")
+    ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32",
+                    help="fp32 (BASELINE configs[1], the default); bf16 MFMA in the decoder/generator (cfg3's dtype); "
+                         "bf16x3: the same convolutions with split operands, three bf16 MFMAs per product (fp32-grade)")
     args = ap.parse_args()
 
     import torch
@@ -57,7 +58,9 @@ def main():
 
     sds = spec.synthetic_state_dicts(0)
     eng = Engine(sds, device=local, precision=args.dtype)
-    bf16 = args.dtype == "bf16"
+    bf16 = args.dtype != "fp32"
+    # peak for ALGORITHMIC flops of the dominant kernel: bf16x3 issues three bf16 MFMAs per algorithmic product
+    peak_tf = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}[args.dtype]
     B, T = args.batch, args.tokens
     rng = np.random.default_rng(1000 + rank)                 # each rank synthesizes different sentences
     ids = np.zeros((B, T), dtype=np.int64)
@@ -140,21 +143,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16 (decoder/generator MFMA operands; fp32 accumulate, activations, durations, F0)" if bf16 else "f32",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (decoder/generator MFMA operands; fp32 accumulate, activations, durations, F0)",
+                      "bf16x3": "f32 emulated on the bf16 matrix pipe in the decoder/generator (operands split hi+lo, 3 MFMAs per "
+                                "product, fp32 accumulate; 2^-16 relative per product); f32 MFMA elsewhere"}[args.dtype],
             "data": "synthetic phoneme ids, seeded random weights of the Kokoro-82M architecture, synthetic voice pack",
-            "config": {"workload": ("configs[1] shape in bf16 mode" if bf16 else "configs[1]") + ": Kokoro-82M, 64 phoneme sequences x 256 tokens per GPU, "
+            "config": {"workload": (f"configs[1] shape in {args.dtype} mode" if bf16 else "configs[1]") + ": Kokoro-82M, 64 phoneme sequences x 256 tokens per GPU, "
                                    "durations predicted by the model", "batch_per_gpu": B, "tokens": T,
                        "frames_per_gpu": int(nfr.sum()), "audio_s_per_step_per_gpu": audio_s,
                        "parallelism": f"dp{world} (sentence sharding, no data-path collective)",
                        "audio_finite": finite},
             "roofline": {
-                "kernel": "conv_mfma_kernel<2,2> (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)",
+                "kernel": "conv_mfma_kernel<2,2> (implicit-GEMM Conv1d, " + ("v_mfma_f32_32x32x16_bf16)" if bf16 else "v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS,
+                "peak": peak_tf,
                 "unit": "TFLOP/s",
-                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS))
-                        if conv_ms > 0 else None,
+                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / peak_tf) if conv_ms > 0 else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "launches_per_step": conv_n / args.steps,

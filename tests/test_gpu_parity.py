@@ -407,3 +407,77 @@ def test_bf16_decoder_mode_snr(engine):
         snr = 10 * np.log10(float(np.sum(a32[s:e].astype(np.float64) ** 2)) / float(np.sum((a32[s:e] - a16[s:e]).astype(np.float64) ** 2)))
         print(f"sentence {b}: bf16 vs fp32 SNR {snr:.1f} dB")
         assert snr >= 40.0
+
+
+@pytest.mark.gpu
+def test_bf16x3_conv_op_is_fp32_grade(engine):
+    """bf16x3 mode (k82_set_precision 2): every operand split as hi + lo (two bf16), three bf16 MFMAs per product,
+    fp32 accumulate.  Representation error 2^-17 per operand, dropped lo*lo term 2^-16: the result must sit
+    within 3e-5 of max|ref| of a float64 reference (the fp32-MFMA mode's own bar is 2e-5), far from plain bf16
+    (~3e-3), and must not be bit-identical to the fp32 mode (the mode really ran)."""
+    import torch
+    rng = np.random.default_rng(6)
+    try:
+        for (cin, cout, L, B, k, dil, act) in [(128, 128, 700, 2, 7, 3, 2), (256, 256, 333, 3, 3, 1, 1), (1090, 1024, 97, 2, 3, 1, 0),
+                                               (130, 256, 260, 1, 11, 5, 2), (16, 128, 1, 1, 3, 1, 0)]:
+            x = rng.standard_normal((B, cin, L)).astype(np.float32)
+            w = (rng.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+            b = rng.standard_normal(cout).astype(np.float32)
+            alpha = (1 + 0.5 * rng.random(cin)).astype(np.float32)
+            kw = dict(dil=dil, act=act, slope=0.2, alpha=alpha if act == 2 else None)
+            engine.set_precision("fp32")
+            y32, _ = engine.op_conv1d(x, w, b, **kw)
+            engine.set_precision("bf16x3")
+            y, _ = engine.op_conv1d(x, w, b, **kw)
+            xt = torch.from_numpy(x).double()
+            if act == 1:
+                xt = torch.nn.functional.leaky_relu(xt, 0.2)
+            elif act == 2:
+                a = torch.from_numpy(alpha).double()[None, :, None]
+                xt = xt + torch.sin(a * xt) ** 2 / a
+            ref = torch.nn.functional.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                             padding=dil * (k - 1) // 2, dilation=dil).numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            err, err32 = float(np.abs(y - ref).max()) / scale, float(np.abs(y32 - ref).max()) / scale
+            print(f"bf16x3 conv cin={cin} cout={cout} k={k} act={act}: err {err:.2e} (fp32 MFMA mode: {err32:.2e})")
+            assert err <= 3e-5
+            assert not np.array_equal(y, y32)
+    finally:
+        engine.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_bf16x3_waveform_meets_fp32_bar(engine, oracle_model):
+    """The bf16x3 mode against the CPU oracle at the fp32 bar (max-abs <= 1e-3, teacher-forced F0/N/har exactly as
+    test_stage_and_waveform_parity): durations bit-exact, F0/N identical to the fp32 mode's (the duration and
+    prosody branches never leave the fp32 matrix instruction)."""
+    id_lists, ref_s = H.make_batch(3, [10, 33, 64])
+    ids, lens = engine.pack(id_lists)
+    engine.debug_enable(True)
+    try:
+        pred32, nfr = engine.durations(ids, lens, ref_s)
+        noise = _noise_for(nfr)
+        a32, off = engine.decode(noise=noise)
+        f0_32 = engine.debug_get("F0").copy()
+        engine.set_precision("bf16x3")
+        pred, nfr3 = engine.durations(ids, lens, ref_s)
+        audio, off3 = engine.decode(noise=noise)
+        assert np.array_equal(pred32, pred) and np.array_equal(off, off3)
+        assert np.array_equal(f0_32, engine.debug_get("F0")) and not np.array_equal(a32, audio)
+        for b, x in enumerate(id_lists):
+            T, F = int(lens[b]), int(nfr[b])
+            nz = noise.reshape(-1, 9)[off[b]:off[b + 1]]
+            f0g = engine.debug_get("F0")[b, 0, :2 * F]
+            ng = engine.debug_get("N")[b, 0, :2 * F]
+            harg = engine.debug_get("har")[b][:22, :120 * F + 1]
+            a_ref, pd = H.oracle_run(oracle_model, x, ref_s[b], 1.0, nz, f0=f0g, n=ng, har=harg)
+            assert np.array_equal(pd, pred[b, :T])
+            err = float(np.abs(audio[off[b]:off[b + 1]] - a_ref).max())
+            err32 = float(np.abs(a32[off[b]:off[b + 1]] - a_ref).max())
+            d = (a32[off[b]:off[b + 1]] - audio[off[b]:off[b + 1]]).astype(np.float64)
+            snr = 10 * np.log10(float(np.sum(a32[off[b]:off[b + 1]].astype(np.float64) ** 2)) / max(float(np.sum(d * d)), 1e-300))
+            print(f"sentence {b}: bf16x3 vs oracle max-abs {err:.2e} (fp32 mode {err32:.2e}); vs fp32 mode SNR {snr:.1f} dB")
+            assert err <= AUDIO_TOL
+    finally:
+        engine.set_precision("fp32")
+        engine.debug_enable(False)

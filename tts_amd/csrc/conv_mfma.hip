@@ -26,6 +26,9 @@
 #ifndef K82_OCC_BF16
 #define K82_OCC_BF16 3              // workgroups per CU (= waves per SIMD) the bf16-mode kernels are built for
 #endif
+#ifndef K82_OCC_SPLIT
+#define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -75,8 +78,20 @@ __device__ __forceinline__ float snake_fast(float v, float al, float ial) {
     return fmaf(ial, sn * sn, v);
 }
 
-template <int WM, int WN, int EPI, bool SNAKE, bool BF16>
-__global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mfma_kernel(ConvP p) {
+//
+// PREC = 2, "bf16x3": fp32-grade products from the bf16 matrix pipe.  Every operand is split into two bf16
+// numbers, v = hi + lo + e with hi = rne_bf16(v), lo = rne_bf16(v - hi), |e| <= 2^-17 |v|, and
+//     a * b  ~=  a_hi b_hi + a_hi b_lo + a_lo b_hi          (the dropped a_lo b_lo term is <= 2^-16 |a b|)
+// is accumulated in fp32 by three v_mfma_f32_32x32x16_bf16 per 16-channel slice: 3/16 of the fp32 matrix time.
+// The split of x happens ONCE, at staging: the LDS tile holds (hi << 16) | lo in the 4 bytes the fp32 value would
+// take, and the B fragments are assembled from 8 ds_read_b32 with 8 v_perm_b32.  The weight image holds the
+// (hi, lo) fragments of a lane side by side (32 bytes).
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
+
+template <int WM, int WN, int EPI, bool SNAKE, int PREC>
+__global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
+    constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
+    constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int BM = 64 * WM, BN = 64 * WN, KC = 16, WP = BN + 68, NW = WM * WN;
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
@@ -189,6 +204,12 @@ __global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mf
                     if constexpr (SNAKE) u = BF16 ? snake_fast(u, alr[cc], ialr[cc]) : snake(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
                     else u = fmaxf(u, u * slope);
                     v[e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
+                    if constexpr (SPLIT) {                    // (hi << 16) | lo, both round-to-nearest-even
+                        const __bf16 hb = (__bf16)v[e];
+                        const __bf16 lb = (__bf16)(v[e] - (float)hb);
+                        v[e] = __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, hb) << 16) |
+                                               (unsigned)__builtin_bit_cast(unsigned short, lb));
+                    }
                 }
                 // lanes past the row end write to a dump slot in the wave's (idle) epilogue patch: no branch
                 float* d = (col < WP) ? dst + c * WP + col : patch + 4 * lane;
@@ -201,7 +222,18 @@ __global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mf
     // dword j of the lane's 16-byte (8 x bf16) fragment, j < 4
     float a0[KC / 2][2], a1[KC / 2][2];
     auto load_a = [&](int m0, int ci0, int tap, float (&a)[KC / 2][2]) {
-        if constexpr (BF16) {
+        if constexpr (SPLIT) {
+            const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
+                              ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31) * 2;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const uint4 u = wp[64 * mi], v = wp[64 * mi + 1];          // hi fragment, lo fragment
+                a[0][mi] = __uint_as_float(u.x); a[1][mi] = __uint_as_float(u.y);
+                a[2][mi] = __uint_as_float(u.z); a[3][mi] = __uint_as_float(u.w);
+                a[4][mi] = __uint_as_float(v.x); a[5][mi] = __uint_as_float(v.y);
+                a[6][mi] = __uint_as_float(v.z); a[7][mi] = __uint_as_float(v.w);
+            }
+        } else if constexpr (BF16) {
             const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
                               ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31);
 #pragma unroll
@@ -226,7 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mf
     // the step, ~2000 cycles after the loads were issued.
     auto rotate_a = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < (BF16 ? 4 : KC / 2); ++kk) {
+        for (int kk = 0; kk < (BF16 && !SPLIT ? 4 : KC / 2); ++kk) {
             asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][0]) : "v"(a1[kk][0]));
             asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][1]) : "v"(a1[kk][1]));
         }
@@ -234,7 +266,30 @@ __global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mf
     // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
     // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
     auto mfma_tap = [&](const float* xsb, int off, const float (&a)[KC / 2][2]) {
-        if constexpr (BF16) {
+        if constexpr (SPLIT) {
+            const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;
+            union { bf16x8 v; unsigned u[4]; } ah[2], al[2], bh, bl;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ah[mi].u[j] = __float_as_uint(a[j][mi]); al[mi].u[j] = __float_as_uint(a[4 + j][mi]); }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned e0 = __float_as_uint(xsp[(2 * j) * WP + 32 * ni]);
+                    const unsigned e1 = __float_as_uint(xsp[(2 * j + 1) * WP + 32 * ni]);
+                    bh.u[j] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // the two high halves
+                    bl.u[j] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // the two low halves
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {                               // small terms first
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].v, bh.v, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].v, bl.v, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].v, bh.v, acc[mi][ni], 0, 0, 0);
+                }
+            }
+        } else if constexpr (BF16) {
             const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;      // lane: channels 8*lhi .. +7, column l31
             union { bf16x8 v; unsigned u[4]; } am[2], bm;
 #pragma unroll
@@ -435,7 +490,7 @@ __global__ __launch_bounds__(64 * WM * WN, BF16 ? K82_OCC_BF16 : 2) void conv_mf
     }
 }
 
-template <int WM, int WN, bool SNAKE, bool BF16>
+template <int WM, int WN, bool SNAKE, int BF16>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     switch (epi) {
     case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_PLAIN, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
@@ -446,12 +501,17 @@ static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
 }
 template <int WM, int WN>
 static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
-    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, false>(p, epi, grid, s);
-    else launch_epi<WM, WN, false, false>(p, epi, grid, s);
+    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32>(p, epi, grid, s);
+    else launch_epi<WM, WN, false, PREC_F32>(p, epi, grid, s);
 }
 static void launch_bf16(const ConvP& p, int epi, unsigned grid, hipStream_t s) {       // 2x2 shape only
-    if (p.act == ACT_SNAKE) launch_epi<2, 2, true, true>(p, epi, grid, s);
-    else launch_epi<2, 2, false, true>(p, epi, grid, s);
+    if (p.wb_split) {
+        if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_SPLIT>(p, epi, grid, s);
+        else launch_epi<2, 2, false, PREC_SPLIT>(p, epi, grid, s);
+    } else {
+        if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_BF16>(p, epi, grid, s);
+        else launch_epi<2, 2, false, PREC_BF16>(p, epi, grid, s);
+    }
 }
 
 // Persistent launch: at most CUS x BLOCKS_PER_CU workgroups walk the output tiles.
@@ -463,7 +523,7 @@ void launch_conv(const ConvP& p, hipStream_t s) {
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
-        const long cap = p.wb ? 256 * K82_OCC_BF16 : kMaxBlocks;
+        const long cap = p.wb ? 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16) : kMaxBlocks;
         const unsigned grid = (unsigned)(total < cap ? total : cap);
         if (p.wb) launch_bf16(p, epi, grid, s);
         else launch_shape<2, 2>(p, epi, grid, s);

@@ -96,6 +96,7 @@ struct HostT { std::vector<float> v; std::vector<int64_t> shape; };
 struct ConvW {
     float* w = nullptr; float* bias = nullptr;
     uint16_t* wb = nullptr;            // bf16 image for the bf16 MFMA mode (2x2 tile shape only)
+    uint16_t* wb2 = nullptr;           // split (hi | lo) bf16 image for the bf16x3 mode
     int cin = 0, cin_p = 0, cout = 0, cout_p = 0, taps = 0, pad = 0;
     unsigned* tapmask = nullptr; int up_s = 0, up_shift = 0;
 };
@@ -197,6 +198,29 @@ struct k82_handle {
         HIPCHK(hipMemcpy(d, o.data(), o.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         return d;
     }
+    // split image for the bf16x3 mode: [tap][cin_p/16][k-half][cout_p][hi 8 | lo 8], w ~= hi + lo to 2^-17 relative
+    uint16_t* upload_split(const std::vector<float>& t, int taps, int cin_p, int cout_p) {
+        if (cout_p % 128 != 0) return nullptr;
+        const int nt = cin_p / 16;
+        std::vector<uint16_t> o((size_t)taps * cin_p * cout_p * 2);
+        for (int kk = 0; kk < taps; ++kk)
+            for (int it = 0; it < nt; ++it)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int co = 0; co < cout_p; ++co)
+                        for (int j = 0; j < 8; ++j) {
+                            const float w = t[((size_t)kk * cin_p + it * 16 + 8 * hh + j) * cout_p + co];
+                            const uint16_t hi = bf16_rne(w);
+                            const uint32_t hu = (uint32_t)hi << 16;
+                            float hf;
+                            std::memcpy(&hf, &hu, 4);
+                            const size_t base = ((((size_t)kk * nt + it) * 2 + hh) * cout_p + co) * 16;
+                            o[base + j] = hi;
+                            o[base + 8 + j] = bf16_rne(w - hf);
+                        }
+        uint16_t* d = (uint16_t*)wmalloc(o.size() * sizeof(uint16_t));
+        HIPCHK(hipMemcpy(d, o.data(), o.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        return d;
+    }
     const HostT& get(const std::string& name, std::initializer_list<int64_t> shape) {
         auto it = host.find(name);
         REQUIRE(it != host.end(), K82_ENOENT, "missing weight tensor: " + name);
@@ -261,6 +285,7 @@ struct k82_handle {
                     t[((size_t)kk * c.cin_p + ci) * c.cout_p + co] = W[((size_t)co * cin + ci) * k + kk];
         c.w = upload(t);
         c.wb = upload_bf16(t, k, c.cin_p, c.cout_p);
+        c.wb2 = upload_split(t, k, c.cin_p, c.cout_p);
         std::vector<float> bp(c.cout_p, 0.f);        // always present, padded to cout_p (the kernel loads it unconditionally)
         if (bias) std::copy(bias->begin(), bias->end(), bp.begin());
         c.bias = upload(bp);
@@ -299,6 +324,7 @@ struct k82_handle {
             for (int co = 0; co < cout; ++co) bp[r * cout + co] = bv.v[co];
         c.w = upload(t);
         c.wb = upload_bf16(t, 3, c.cin_p, c.cout_p);
+        c.wb2 = upload_split(t, 3, c.cin_p, c.cout_p);
         c.bias = upload(bp);
         std::vector<unsigned> mask(c.cout_p / 64, 0x7u);
         for (size_t mt = 0; mt < mask.size(); ++mt) {
@@ -482,7 +508,8 @@ struct k82_handle {
         std::memset(&p, 0, sizeof(p));
         p.x = x; p.xbs = xbs; p.xpitch = xpitch;
         p.w = w.w; p.bias = w.bias;
-        p.wb = bf16_now ? w.wb : nullptr;
+        p.wb = bf16_now ? (precision == 2 ? w.wb2 : w.wb) : nullptr;
+        p.wb_split = bf16_now && precision == 2 && w.wb2;
         p.y = y; p.ybs = ybs; p.ypitch = ypitch;
         p.lin = lin; p.lout = lout;
         p.cin = w.cin; p.cin_p = w.cin_p; p.cout = w.cout; p.cout_p = w.cout_p; p.taps = w.taps;
@@ -791,7 +818,7 @@ struct k82_handle {
         // convs take their bf16 weight image; everything before (durations, F0/N curves, text encoder) and
         // conv_post (1x4 shape) stay on the exact-fp32 instruction.  The guard clears the flag on any exit.
         struct Bf16Scope { bool& f; ~Bf16Scope() { f = false; } } bf16_scope{bf16_now};
-        bf16_now = precision == 1;
+        bf16_now = precision != 0;
         resblk1d(enc, cat0, c0bs, PF, lF, Fmax, hb, sumF, catA, c1bs, PF, gbd, Gd, aF);
         tap("dec_encode", catA, 1024, PF, c1bs, nb);
         for (float* cat : {catA, catB}) {
@@ -1057,7 +1084,7 @@ int k82_debug_copy(k82_handle* h, const char* name, float* dst) {
 
 int k82_set_precision(k82_handle* h, int mode) {
     return guarded(h, nullptr, [&] {
-        REQUIRE(mode == 0 || mode == 1, K82_EINVAL, "precision mode must be 0 (fp32) or 1 (bf16 decoder/generator MFMA)");
+        REQUIRE(mode >= 0 && mode <= 2, K82_EINVAL, "precision mode must be 0 (fp32), 1 (bf16 decoder/generator MFMA) or 2 (bf16x3 split)");
         h->precision = mode;
     });
 }
@@ -1094,7 +1121,8 @@ int k82_op_conv1d(k82_handle* h, const float* x, const float* w, const float* bi
         const LenSpec ls{nullptr, 0, L};
         ConvP p = h->cp(cw, xd, (long)cw.cin_p * P, P, yd, (long)cout * P, P, ls, ls, B, L, dil);
         p.act = act; p.slope = slope; p.alpha = ad; p.inv_alpha = iad;
-        p.wb = h->precision == 1 ? cw.wb : nullptr;          // the op hook follows k82_set_precision directly
+        p.wb = h->precision == 1 ? cw.wb : h->precision == 2 ? cw.wb2 : nullptr;    // the op hook follows k82_set_precision directly
+        p.wb_split = h->precision == 2 && cw.wb2;
         k82_handle::check_conv(p);
         launch_conv(p, h->st);
         if (iters > 1 || ms) {

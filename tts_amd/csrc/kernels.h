@@ -26,6 +26,8 @@ struct ConvP {
     const float* w;                            // weights [taps][cin_p][cout_p] (tap-major, cout contiguous)
     const uint16_t* wb;                        // bf16 image of the same weights (nullptr: fp32 MFMA):
                                                // [taps][cin_p/16][2 k-halves][cout_p][8], 16 B per (row, k-half)
+    int wb_split;                              // 1: wb is the split image [..][cout_p][hi 8 | lo 8] (32 B per row and
+                                               // k-half), hi = rne_bf16(w), lo = rne_bf16(w - hi): the bf16x3 mode
     const float* bias;                         // [cout_p] or nullptr
     float* y; long ybs; int ypitch;            // output (nullptr: accumulate only)
     LenSpec lin, lout;                         // input / output valid lengths

@@ -67,10 +67,12 @@ class Engine:
         self.set_precision(precision)
 
     def set_precision(self, precision):
-        """"fp32" (default) or "bf16": bf16 MFMA for the decoder / generator convolutions (k82_set_precision)."""
-        mode = {"fp32": 0, "f32": 0, "bf16": 1}[precision]
+        """"fp32" (default), "bf16" (bf16 MFMA for the decoder / generator convolutions) or "bf16x3" (the same
+        convolutions with every operand split into two bf16 numbers and three MFMAs per product: fp32-grade
+        results from the bf16 matrix pipe) -- k82_set_precision."""
+        mode = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}[precision]
         self._check(self.lib.k82_set_precision(self.h, mode))
-        self.precision = "bf16" if mode else "fp32"
+        self.precision = ("fp32", "bf16", "bf16x3")[mode]
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
