@@ -218,61 +218,35 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         }
     };
 
-    // A fragments of the tap being consumed / the next one.  fp32: [kk][mi] scalars; bf16: element [j][mi] is
-    // dword j of the lane's 16-byte (8 x bf16) fragment, j < 4
-    float a0[KC / 2][2], a1[KC / 2][2];
-    auto load_a = [&](int m0, int ci0, int tap, float (&a)[KC / 2][2]) {
+    // Two sets of A fragments: the one being consumed and the one being loaded.  fp32: f[kk][mi] scalars;
+    // bf16 modes: q[] are the lane's 16-byte fragments exactly as loaded (q[mi], or q[2 mi] = hi / q[2 mi + 1] = lo
+    // in the split mode) -- kept as whole 4-register tuples so the load's destination IS the MFMA operand.
+    struct ASet { float f[KC / 2][2]; uint4 q[4]; };
+    ASet a0, a1;
+    auto load_a = [&](int m0, int ci0, int tap, ASet& a) {
         if constexpr (SPLIT) {
             const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
                               ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31) * 2;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const uint4 u = wp[64 * mi], v = wp[64 * mi + 1];          // hi fragment, lo fragment
-                a[0][mi] = __uint_as_float(u.x); a[1][mi] = __uint_as_float(u.y);
-                a[2][mi] = __uint_as_float(u.z); a[3][mi] = __uint_as_float(u.w);
-                a[4][mi] = __uint_as_float(v.x); a[5][mi] = __uint_as_float(v.y);
-                a[6][mi] = __uint_as_float(v.z); a[7][mi] = __uint_as_float(v.w);
-            }
+            a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65];
         } else if constexpr (BF16) {
             const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
                               ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const uint4 u = wp[32 * mi];
-                a[0][mi] = __uint_as_float(u.x); a[1][mi] = __uint_as_float(u.y);
-                a[2][mi] = __uint_as_float(u.z); a[3][mi] = __uint_as_float(u.w);
-            }
+            a.q[0] = wp[0]; a.q[1] = wp[32];
         } else {
             const float* wp = p.w + ((long)(tap * p.cin_p + ci0 + lhi) * p.cout_p) + m0 + l31;
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
-                a[kk][0] = wp[(long)(2 * kk) * p.cout_p];
-                a[kk][1] = wp[(long)(2 * kk) * p.cout_p + 32];
+                a.f[kk][0] = wp[(long)(2 * kk) * p.cout_p];
+                a.f[kk][1] = wp[(long)(2 * kk) * p.cout_p + 32];
             }
-        }
-    };
-    // a0 <- a1 through opaque moves.  With plain copies hipcc coalesces a1 into a0 across the loop; with a0
-    // loaded directly in the prologue its wait-count pass merges "a0 may still be in flight" into the loop
-    // header.  Either way the MFMAs of a step end up waiting (in-order vmcnt) for the x and A loads issued
-    // just before them -- one exposed memory round trip per ci-tile.  The moves pin the wait to the end of
-    // the step, ~2000 cycles after the loads were issued.
-    auto rotate_a = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < (BF16 && !SPLIT ? 4 : KC / 2); ++kk) {
-            asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][0]) : "v"(a1[kk][0]));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(a0[kk][1]) : "v"(a1[kk][1]));
         }
     };
     // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
     // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
-    auto mfma_tap = [&](const float* xsb, int off, const float (&a)[KC / 2][2]) {
+    auto mfma_tap = [&](const float* xsb, int off, const ASet& a) {
         if constexpr (SPLIT) {
             const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;
-            union { bf16x8 v; unsigned u[4]; } ah[2], al[2], bh, bl;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { ah[mi].u[j] = __float_as_uint(a[j][mi]); al[mi].u[j] = __float_as_uint(a[4 + j][mi]); }
+            union { bf16x8 v; unsigned u[4]; } bh, bl;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -284,24 +258,21 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {                               // small terms first
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].v, bh.v, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].v, bl.v, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].v, bh.v, acc[mi][ni], 0, 0, 0);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.q[2 * mi]), al = __builtin_bit_cast(bf16x8, a.q[2 * mi + 1]);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh.v, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl.v, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh.v, acc[mi][ni], 0, 0, 0);
                 }
             }
         } else if constexpr (BF16) {
             const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;      // lane: channels 8*lhi .. +7, column l31
-            union { bf16x8 v; unsigned u[4]; } am[2], bm;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) am[mi].u[j] = __float_as_uint(a[j][mi]);
+            union { bf16x8 v; unsigned u[4]; } bm;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bm.v[j] = (__bf16)xsp[j * WP + 32 * ni];
-                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0].v, bm.v, acc[0][ni], 0, 0, 0);
-                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1].v, bm.v, acc[1][ni], 0, 0, 0);
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[0]), bm.v, acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[1]), bm.v, acc[1][ni], 0, 0, 0);
             }
         } else {
             const float* xsp = xsb + lhi * WP + nw + l31 + off;
@@ -309,10 +280,10 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             for (int kk = 0; kk < KC / 2; ++kk) {
                 const float b0 = xsp[2 * kk * WP];
                 const float b1 = xsp[2 * kk * WP + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][0], b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][1], b1, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b1, acc[1][1], 0, 0, 0);
             }
         }
     };
@@ -431,8 +402,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     if (q < 0) return;
     load_tile(cur, 0);
     write_tile(cur, 0, lds);
-    load_a(cur.m0, 0, cur.tap0, a1);
-    rotate_a();
+    load_a(cur.m0, 0, cur.tap0, a0);
     __syncthreads();
     int g = 0;                                   // parity of the LDS buffer holding the current ci-tile
     while (true) {
@@ -458,29 +428,74 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             S.tbase = more ? cur.tbase : nxt.tbase;
             S.tap0 = more ? cur.tap0 : nxt.tap0;
             const int sci0 = more ? ci0 + KC : 0;
-            {   // first active tap: stage + compute
-                const bool single = cur.nact == 1;
-                const int ntap = single ? S.tap0 : next_tap(tap);
-                load_tile(S, sci0);
-                load_a(single ? S.m0 : cur.m0, single ? sci0 : ci0, ntap, a1);
-                __builtin_amdgcn_sched_barrier(0);     // loads are issued BEFORE the MFMAs (the scheduler sinks them otherwise)
-                mfma_tap(xsb, tap * p.dil + cur.shift, a0);
-                __builtin_amdgcn_sched_barrier(0);     // ... and waited for only after the MFMAs are in the pipe
-                write_tile(S, sci0, xsn);
-                tap = ntap;
-                rotate_a();
+            // The taps of one ci-tile ping-pong between the two fragment sets: even steps compute from a0 while
+            // the loads of the next step fill a1, odd steps the other way round -- no register rotation per tap
+            // (16 v_mov, each of which costs the SIMD ~10 cycles that the partner wave's MFMAs do not cover) and no
+            // wait at the end of a step.  Every ci-tile starts from a0, so an ODD tap count ends with one rotation
+            // a0 <- a1 (through opaque moves: plain copies are coalesced across the loop and the MFMAs then wait,
+            // in-order vmcnt, for the loads issued just before them).
+            ASet& X = a0;
+            ASet& Y = a1;
+            {
+                {   // first active tap: stage + compute
+                    const bool single = cur.nact == 1;
+                    const int ntap = single ? S.tap0 : next_tap(tap);
+                    load_tile(S, sci0);
+                    load_a(single ? S.m0 : cur.m0, single ? sci0 : ci0, ntap, Y);
+                    __builtin_amdgcn_sched_barrier(0);     // loads are issued BEFORE the MFMAs (the scheduler sinks them otherwise)
+                    mfma_tap(xsb, tap * p.dil + cur.shift, X);
+                    __builtin_amdgcn_sched_barrier(0);     // ... and waited for only after the MFMAs are in the pipe
+                    write_tile(S, sci0, xsn);
+                    tap = ntap;
+                }
+                int j = 1;
+                for (; j + 1 < cur.nact; j += 2) {         // two taps per trip: compute from Y, then from X
+                    {
+                        const int ntap = next_tap(tap);
+                        load_a(cur.m0, ci0, ntap, X);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_tap(xsb, tap * p.dil + cur.shift, Y);
+                        __builtin_amdgcn_sched_barrier(0);
+                        tap = ntap;
+                    }
+                    {
+                        const bool last = j + 2 == cur.nact;
+                        const int ntap = last ? S.tap0 : next_tap(tap);
+                        load_a(last ? S.m0 : cur.m0, last ? sci0 : ci0, ntap, Y);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_tap(xsb, tap * p.dil + cur.shift, X);
+                        __builtin_amdgcn_sched_barrier(0);
+                        tap = ntap;
+                    }
+                }
+                if (j < cur.nact) {                        // an even tap count leaves one step: the last
+                    load_a(S.m0, sci0, S.tap0, X);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tap(xsb, tap * p.dil + cur.shift, Y);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap = S.tap0;
+                }
+                if (cur.nact & 1) {
+                    if constexpr (BF16) {
+#pragma unroll
+                        for (int i = 0; i < (SPLIT ? 4 : 2); ++i) {
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].x) : "v"(a1.q[i].x));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].y) : "v"(a1.q[i].y));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].z) : "v"(a1.q[i].z));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].w) : "v"(a1.q[i].w));
+                        }
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < KC / 2; ++kk) {
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.f[kk][0]) : "v"(a1.f[kk][0]));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.f[kk][1]) : "v"(a1.f[kk][1]));
+                        }
+                    }
+                }
             }
-            for (int j = 1; j < cur.nact; ++j) {
-                const bool last = j == cur.nact - 1;
-                const int ntap = last ? S.tap0 : next_tap(tap);
-                load_a(last ? S.m0 : cur.m0, last ? sci0 : ci0, ntap, a1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_tap(xsb, tap * p.dil + cur.shift, a0);
-                __builtin_amdgcn_sched_barrier(0);
-                tap = ntap;
-                rotate_a();
-            }
-            __syncthreads();
+            // raw barrier: LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e. wait here for the
+            // weight fragments just requested for the next ci-tile.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ++g;
         }
         epilogue(cur, bias_l);
