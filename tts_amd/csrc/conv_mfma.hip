@@ -32,6 +32,13 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// (bf16(a), bf16(b)) packed into one dword, a in the low half: one v_cvt_pk_bf16_f32 (round-to-nearest-even)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((floatx2){a, b}, bf16x2));
+}
 
 __device__ __forceinline__ float gelu_new(float x) {
     const float k = 0.7978845608028654f;   // sqrt(2/pi)
@@ -65,11 +72,11 @@ __device__ __forceinline__ float snake(float v, float al, float ial) {
 //   EPI_SCALAR transposed-conv phase interleave (up_s) / x2 nearest residual (res_shift): dword path
 enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3 };
 
-// BF16 = true: same staging, same epilogues, but the MFMAs are v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
-// the A operand is the pre-packed bf16 weight image (one 16-byte load per lane, row and k-half), the B operand
-// is read from the fp32 LDS tile (8 ds_read_b32 down the channel axis) and rounded to bf16 in registers
-// (v_cvt_pk_bf16_f32, round-to-nearest-even).  One MFMA covers the whole 16-channel tile of a tap, so the
-// matrix pipe needs 1/16 of the fp32 time and the kernel becomes a streaming (HBM / staging bound) kernel.
+// PREC = 1 (bf16): same staging, same epilogues, but the MFMAs are v_mfma_f32_32x32x16_bf16 (fp32 accumulate): the
+// A operand is the pre-packed bf16 weight image (one 16-byte load per lane, row and k-half), the B operand is the
+// staged x tile rounded to bf16 (round-to-nearest-even) when it is written to LDS.  One MFMA covers the whole
+// 16-channel tile of a tap, so the matrix pipe needs 1/16 of the fp32 time and the kernel becomes a streaming
+// (HBM / staging bound) kernel.
 // bf16 mode only: sin through the hardware v_sin_f32 (argument in revolutions, ~1e-6 absolute error for the
 // |alpha v| < 256 * 2 pi this model produces): 4 instructions instead of 14 -- in bf16 mode the staging VALU, not
 // the matrix pipe, is what the Snake convolutions wait for.
@@ -83,9 +90,12 @@ __device__ __forceinline__ float snake_fast(float v, float al, float ial) {
 // numbers, v = hi + lo + e with hi = rne_bf16(v), lo = rne_bf16(v - hi), |e| <= 2^-17 |v|, and
 //     a * b  ~=  a_hi b_hi + a_hi b_lo + a_lo b_hi          (the dropped a_lo b_lo term is <= 2^-16 |a b|)
 // is accumulated in fp32 by three v_mfma_f32_32x32x16_bf16 per 16-channel slice: 3/16 of the fp32 matrix time.
-// The split of x happens ONCE, at staging: the LDS tile holds (hi << 16) | lo in the 4 bytes the fp32 value would
-// take, and the B fragments are assembled from 8 ds_read_b32 with 8 v_perm_b32.  The weight image holds the
-// (hi, lo) fragments of a lane side by side (32 bytes).
+// The split of x happens ONCE, at staging.  In both bf16 modes the LDS tile is stored in MFMA-operand order: a dword
+// holds the bf16 values of one column for the channel PAIR (2q, 2q+1), rows [q = 0..7][column] (plus the same 8 rows
+// of lo parts in the split mode), so dword j of a lane's B fragment is one conflict-free ds_read_b32 -- no
+// conversion or byte shuffling in the tap loop (VALU instructions there cost the SIMD ~10 cycles each that the
+// partner wave's MFMAs do not cover).  A wave stages two channel pairs per ci-tile, packing with v_cvt_pk_bf16_f32.
+// The weight image holds the (hi, lo) fragments of a lane side by side (32 bytes).
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
 
 template <int WM, int WN, int EPI, bool SNAKE, int PREC>
@@ -150,6 +160,10 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
 
+    // channel (within the ci-tile) that staging slot cc of this wave carries: fp32 w, w+NW, ...; bf16 modes the
+    // channel pairs (2w, 2w+1) and (8+2w, 8+2w+1), i.e. rows w and 4+w of the packed tile
+    auto chan = [&](int cc) -> int { return BF16 ? 2 * wave + (cc & 1) + 8 * (cc >> 1) : wave + cc * NW; };
+    static_assert(!BF16 || (NW == 4 && CPW == 4), "the packed bf16 staging assumes 4 waves x 4 channels");
     float4 raw[CPW][NCOL], nmr[CPW];
     float alr[CPW], ialr[CPW];
     // Per-channel transform parameters always come from a readable address (the padded bias vector stands
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         const int tlast = ((T.Lin - 1) >> 2) << 2;          // last aligned float4 that starts inside the row
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
-            const int ci = min(ci0 + wave + cc * NW, p.cin - 1);
+            const int ci = min(ci0 + chan(cc), p.cin - 1);
             const float* xr = xb + (long)ci * p.xpitch;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
@@ -187,34 +201,56 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     // LeakyReLU is max(u, slope * u) (slope in [0, 1], checked on the host), validity is one unsigned
     // compare against the row length (0 for padded channels).
     auto write_tile = [&](const Tile& T, int ci0, float* dst) {
+        float out[CPW][NCOL][4];
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
-            const int c = wave + cc * NW;
-            const unsigned lin = (ci0 + c < p.cin) ? (unsigned)T.Lin : 0u;
+            const unsigned lin = (ci0 + chan(cc) < p.cin) ? (unsigned)T.Lin : 0u;
             const float4 nm = (p.tr == TR_NORM) ? nmr[cc] : nid;
             const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const int col = 4 * (lane + 64 * k);
-                const unsigned t = (unsigned)(T.tbase + col);
-                float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
+                const unsigned t = (unsigned)(T.tbase + 4 * (lane + 64 * k));
+                const float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float u = fmaf(v[e], sc, of);
                     if constexpr (SNAKE) u = BF16 ? snake_fast(u, alr[cc], ialr[cc]) : snake(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
                     else u = fmaxf(u, u * slope);
-                    v[e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
-                    if constexpr (SPLIT) {                    // (hi << 16) | lo, both round-to-nearest-even
-                        const __bf16 hb = (__bf16)v[e];
-                        const __bf16 lb = (__bf16)(v[e] - (float)hb);
-                        v[e] = __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, hb) << 16) |
-                                               (unsigned)__builtin_bit_cast(unsigned short, lb));
+                    out[cc][k][e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
+                }
+            }
+        }
+        // lanes past the row end write to a dump slot in the wave's (idle) epilogue patch: no branch
+        if constexpr (!BF16) {
+#pragma unroll
+            for (int cc = 0; cc < CPW; ++cc)
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) {
+                    const int col = 4 * (lane + 64 * k);
+                    float* d = (col < WP) ? dst + chan(cc) * WP + col : patch + 4 * lane;
+                    *reinterpret_cast<float4*>(d) = make_float4(out[cc][k][0], out[cc][k][1], out[cc][k][2], out[cc][k][3]);
+                }
+        } else {
+#pragma unroll
+            for (int pr = 0; pr < CPW / 2; ++pr)
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) {
+                    const int col = 4 * (lane + 64 * k);
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u0 = out[2 * pr][k][e], u1 = out[2 * pr + 1][k][e];
+                        hi[e] = pack_bf16(u0, u1);
+                        if constexpr (SPLIT)
+                            lo[e] = pack_bf16(u0 - __uint_as_float(hi[e] << 16), u1 - __uint_as_float(hi[e] & 0xffff0000u));
+                    }
+                    float* d = (col < WP) ? dst + (wave + 4 * pr) * WP + col : patch + 4 * lane;
+                    *reinterpret_cast<uint4*>(d) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                    if constexpr (SPLIT) {
+                        float* d2 = (col < WP) ? dst + (8 + wave + 4 * pr) * WP + col : patch + 4 * lane;
+                        *reinterpret_cast<uint4*>(d2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
                     }
                 }
-                // lanes past the row end write to a dump slot in the wave's (idle) epilogue patch: no branch
-                float* d = (col < WP) ? dst + c * WP + col : patch + 4 * lane;
-                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-            }
         }
     };
 
@@ -244,36 +280,34 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
     // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
     auto mfma_tap = [&](const float* xsb, int off, const ASet& a) {
-        if constexpr (SPLIT) {
-            const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;
-            union { bf16x8 v; unsigned u[4]; } bh, bl;
+        if constexpr (BF16) {
+            // lane: channel pairs 4*lhi .. +3 (rows of the packed tile), column l31.  The two column halves are read
+            // as separate groups (the compiler fence keeps the load merger from pairing ni = 0 with ni = 1 dwords,
+            // which belong to different operand tuples and would have to be copied apart again)
+            const float* xsp = xsb + (4 * lhi) * WP + nw + l31 + off;
+            union { bf16x8 v; unsigned u[4]; } bh[2], bl[2];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const unsigned e0 = __float_as_uint(xsp[(2 * j) * WP + 32 * ni]);
-                    const unsigned e1 = __float_as_uint(xsp[(2 * j + 1) * WP + 32 * ni]);
-                    bh.u[j] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // the two high halves
-                    bl.u[j] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // the two low halves
+                    bh[ni].u[j] = __float_as_uint(xsp[j * WP + 32 * ni]);
+                    if constexpr (SPLIT) bl[ni].u[j] = __float_as_uint(xsp[(8 + j) * WP + 32 * ni]);
                 }
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {                               // small terms first
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.q[2 * mi]), al = __builtin_bit_cast(bf16x8, a.q[2 * mi + 1]);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh.v, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl.v, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh.v, acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    if constexpr (SPLIT) {                                     // small terms first
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, a.q[2 * mi]), al = __builtin_bit_cast(bf16x8, a.q[2 * mi + 1]);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni].v, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni].v, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni].v, acc[mi][ni], 0, 0, 0);
+                    } else {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[mi]), bh[ni].v, acc[mi][ni], 0, 0, 0);
+                    }
                 }
-            }
-        } else if constexpr (BF16) {
-            const float* xsp = xsb + (8 * lhi) * WP + nw + l31 + off;      // lane: channels 8*lhi .. +7, column l31
-            union { bf16x8 v; unsigned u[4]; } bm;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bm.v[j] = (__bf16)xsp[j * WP + 32 * ni];
-                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[0]), bm.v, acc[0][ni], 0, 0, 0);
-                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[1]), bm.v, acc[1][ni], 0, 0, 0);
-            }
         } else {
             const float* xsp = xsb + lhi * WP + nw + l31 + off;
 #pragma unroll
