@@ -279,35 +279,49 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     };
     // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
     // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
-    auto mfma_tap = [&](const float* xsb, int off, const ASet& a) {
-        if constexpr (BF16) {
-            // lane: channel pairs 4*lhi .. +3 (rows of the packed tile), column l31.  The two column halves are read
-            // as separate groups (the compiler fence keeps the load merger from pairing ni = 0 with ni = 1 dwords,
-            // which belong to different operand tuples and would have to be copied apart again)
-            const float* xsp = xsb + (4 * lhi) * WP + nw + l31 + off;
-            union { bf16x8 v; unsigned u[4]; } bh[2], bl[2];
+    // bf16 modes: B fragments of one 32-column half.  bpre carries the ni = 0 half of the NEXT step across steps:
+    // it is read while the MFMAs of the current step's second half run, so the only LDS latency a wave exposes is
+    // the first read after each barrier (the two waves of a SIMD tend to run in phase, so an exposed read stalls
+    // the matrix pipe for both).
+    struct BFrag { union { bf16x8 v; unsigned u[4]; } h, l; };
+    BFrag bpre;
+    auto read_b = [&](const float* xsb, int off, int ni, BFrag& f) {
+        // lane: channel pairs 4*lhi .. +3 (rows of the packed tile), column l31.  One group per column half: the
+        // compiler fence keeps the load merger from pairing ni = 0 with ni = 1 dwords, which belong to different
+        // operand tuples and would have to be copied apart again
+        const float* xsp = xsb + (4 * lhi) * WP + nw + l31 + off + 32 * ni;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+        for (int j = 0; j < 4; ++j) {
+            f.h.u[j] = __float_as_uint(xsp[j * WP]);
+            if constexpr (SPLIT) f.l.u[j] = __float_as_uint(xsp[(8 + j) * WP]);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto mma_half = [&](const ASet& a, int ni, const BFrag& f) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bh[ni].u[j] = __float_as_uint(xsp[j * WP + 32 * ni]);
-                    if constexpr (SPLIT) bl[ni].u[j] = __float_as_uint(xsp[(8 + j) * WP + 32 * ni]);
-                }
-                asm volatile("" ::: "memory");
+        for (int mi = 0; mi < 2; ++mi) {
+            if constexpr (SPLIT) {                                     // small terms first
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, a.q[2 * mi]), al = __builtin_bit_cast(bf16x8, a.q[2 * mi + 1]);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f.h.v, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.l.v, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.h.v, acc[mi][ni], 0, 0, 0);
+            } else {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[mi]), f.h.v, acc[mi][ni], 0, 0, 0);
             }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    if constexpr (SPLIT) {                                     // small terms first
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, a.q[2 * mi]), al = __builtin_bit_cast(bf16x8, a.q[2 * mi + 1]);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni].v, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni].v, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni].v, acc[mi][ni], 0, 0, 0);
-                    } else {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[mi]), bh[ni].v, acc[mi][ni], 0, 0, 0);
-                    }
-                }
+        }
+    };
+    // offn: column offset of the next tap of the SAME ci-tile (any valid offset when there is none: the prefetched
+    // fragments are then simply not used -- the first step after the barrier reads its own)
+    auto mfma_tap = [&](const float* xsb, int off, int offn, const ASet& a) {
+        if constexpr (BF16) {
+            BFrag f1;
+            read_b(xsb, off, 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(a, 0, bpre);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(xsb, offn, 0, bpre);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(a, 1, f1);
         } else {
             const float* xsp = xsb + lhi * WP + nw + l31 + off;
 #pragma unroll
@@ -470,6 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             // in-order vmcnt, for the loads issued just before them).
             ASet& X = a0;
             ASet& Y = a1;
+            if constexpr (BF16) read_b(xsb, tap * p.dil + cur.shift, 0, bpre);
             {
                 {   // first active tap: stage + compute
                     const bool single = cur.nact == 1;
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                     load_tile(S, sci0);
                     load_a(single ? S.m0 : cur.m0, single ? sci0 : ci0, ntap, Y);
                     __builtin_amdgcn_sched_barrier(0);     // loads are issued BEFORE the MFMAs (the scheduler sinks them otherwise)
-                    mfma_tap(xsb, tap * p.dil + cur.shift, X);
+                    mfma_tap(xsb, tap * p.dil + cur.shift, ntap * p.dil + cur.shift, X);    // (single: ntap is a tap of this conv too)
                     __builtin_amdgcn_sched_barrier(0);     // ... and waited for only after the MFMAs are in the pipe
                     write_tile(S, sci0, xsn);
                     tap = ntap;
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                         const int ntap = next_tap(tap);
                         load_a(cur.m0, ci0, ntap, X);
                         __builtin_amdgcn_sched_barrier(0);
-                        mfma_tap(xsb, tap * p.dil + cur.shift, Y);
+                        mfma_tap(xsb, tap * p.dil + cur.shift, ntap * p.dil + cur.shift, Y);
                         __builtin_amdgcn_sched_barrier(0);
                         tap = ntap;
                     }
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                         const int ntap = last ? S.tap0 : next_tap(tap);
                         load_a(last ? S.m0 : cur.m0, last ? sci0 : ci0, ntap, Y);
                         __builtin_amdgcn_sched_barrier(0);
-                        mfma_tap(xsb, tap * p.dil + cur.shift, X);
+                        mfma_tap(xsb, tap * p.dil + cur.shift, ntap * p.dil + cur.shift, X);
                         __builtin_amdgcn_sched_barrier(0);
                         tap = ntap;
                     }
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                 if (j < cur.nact) {                        // an even tap count leaves one step: the last
                     load_a(S.m0, sci0, S.tap0, X);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_tap(xsb, tap * p.dil + cur.shift, Y);
+                    mfma_tap(xsb, tap * p.dil + cur.shift, tap * p.dil + cur.shift, Y);
                     __builtin_amdgcn_sched_barrier(0);
                     tap = S.tap0;
                 }
