@@ -26,7 +26,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--max-sentences", type=int, default=0)
 ap.add_argument("--latency-sentences", type=int, default=200)
 ap.add_argument("--max-batch", type=int, default=256)
-ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32")
+ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32")
 args = ap.parse_args()
 
 G = os.path.join(ROOT, "tests", "golden")

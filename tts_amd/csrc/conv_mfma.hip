@@ -98,6 +98,12 @@ __device__ __forceinline__ float snake_fast(float v, float al, float ial) {
 // The weight image holds the (hi, lo) fragments of a lane side by side (32 bytes).
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
 
+//
+// (Measured and not kept: a 512-thread workgroup per CU holding two wave groups that alternate, one barrier-separated
+// slot out of step, between a compute slot (all taps of a ci-tile) and a stage slot (transform / split / LDS writes /
+// epilogue), so that every SIMD always pairs a matrix-bound wave with a VALU-bound one.  Correct, but 5-10 % slower
+// in the split mode and 20-35 % slower in the bf16 mode than two free-running 256-thread workgroups: a lone wave's
+// tap step is bound by its own in-order issue -- weight loads, LDS reads, waits, 12 MFMAs -- not by the partner.)
 template <int WM, int WN, int EPI, bool SNAKE, int PREC>
 __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
@@ -259,26 +265,29 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     // in the split mode) -- kept as whole 4-register tuples so the load's destination IS the MFMA operand.
     struct ASet { float f[KC / 2][2]; uint4 q[4]; };
     ASet a0, a1;
+    // Addresses are (wave-uniform 64-bit base in SGPRs) + (32-bit lane offset in one VGPR): the per-tap address
+    // arithmetic runs on the scalar unit and the loads use the saddr form -- vector instructions in the tap loop
+    // compete with the MFMAs for issue, scalar ones do not.
+    const unsigned a_lane = BF16 ? (unsigned)((lhi * p.cout_p + l31) * (SPLIT ? 32 : 16))
+                                 : (unsigned)((lhi * p.cout_p + l31) * 4);
     auto load_a = [&](int m0, int ci0, int tap, ASet& a) {
-        if constexpr (SPLIT) {
-            const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
-                              ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31) * 2;
-            a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65];
-        } else if constexpr (BF16) {
-            const uint4* wp = reinterpret_cast<const uint4*>(p.wb) +
-                              ((long)((tap * ntiles + ci0 / KC) * 2 + lhi) * p.cout_p + m0 + l31);
-            a.q[0] = wp[0]; a.q[1] = wp[32];
+        if constexpr (BF16) {
+            constexpr int FB = SPLIT ? 32 : 16;                // bytes per (row, k-half): hi | lo fragments, or one
+            const char* base = reinterpret_cast<const char*>(p.wb) +
+                               ((long)((tap * ntiles + ci0 / KC) * 2) * p.cout_p + m0) * FB;
+            const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
+            if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65]; }
+            else { a.q[0] = wp[0]; a.q[1] = wp[32]; }
         } else {
-            const float* wp = p.w + ((long)(tap * p.cin_p + ci0 + lhi) * p.cout_p) + m0 + l31;
+            const char* base = reinterpret_cast<const char*>(p.w) + ((long)(tap * p.cin_p + ci0) * p.cout_p + m0) * 4;
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
-                a.f[kk][0] = wp[(long)(2 * kk) * p.cout_p];
-                a.f[kk][1] = wp[(long)(2 * kk) * p.cout_p + 32];
+                const float* wp = reinterpret_cast<const float*>(base + (long)(2 * kk) * p.cout_p * 4 + a_lane);
+                a.f[kk][0] = wp[0];
+                a.f[kk][1] = wp[32];
             }
         }
     };
-    // One tap of one ci-tile.  (Forcing all 16 B reads ahead of the 32 MFMAs with a scheduling barrier
-    // measured 2-4 % slower than the compiler's read-per-four-MFMAs order, same box.)
     // bf16 modes: B fragments of one 32-column half.  bpre carries the ni = 0 half of the NEXT step across steps:
     // it is read while the MFMAs of the current step's second half run, so the only LDS latency a wave exposes is
     // the first read after each barrier (the two waves of a SIMD tend to run in phase, so an exposed read stalls
@@ -568,7 +577,9 @@ static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) 
     if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32>(p, epi, grid, s);
     else launch_epi<WM, WN, false, PREC_F32>(p, epi, grid, s);
 }
-static void launch_bf16(const ConvP& p, int epi, unsigned grid, hipStream_t s) {       // 2x2 shape only
+static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {       // 2x2 shape only
+    const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (p.wb_split) {
         if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_SPLIT>(p, epi, grid, s);
         else launch_epi<2, 2, false, PREC_SPLIT>(p, epi, grid, s);
@@ -587,10 +598,8 @@ void launch_conv(const ConvP& p, hipStream_t s) {
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
-        const long cap = p.wb ? 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16) : kMaxBlocks;
-        const unsigned grid = (unsigned)(total < cap ? total : cap);
-        if (p.wb) launch_bf16(p, epi, grid, s);
-        else launch_shape<2, 2>(p, epi, grid, s);
+        if (p.wb) launch_bf16(p, epi, total, s);
+        else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
         launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
