@@ -66,8 +66,10 @@ def _load_model(model_path, voices_path, device):
 class Kokoro:
     """Drop-in for ``kokoro_onnx.Kokoro`` (pinned 0.4.9, io.github.fastrizwaan.tts.yaml:890-901)."""
 
-    def __init__(self, model_path: str, voices_path: str, device: int = 0):
+    def __init__(self, model_path: str, voices_path: str, device: int = 0, precision: str = "fp32"):
         self.engine, self.config, self.vocab, self.voices = _load_model(model_path, voices_path, device)
+        if precision != "fp32":          # "bf16" / "bf16x3": k82_set_precision (no counterpart in the reference)
+            self.engine.set_precision(precision)
         self.synth = BatchSynthesizer(self.engine)
         self._seed = 0
         self._seed_lock = threading.Lock()
