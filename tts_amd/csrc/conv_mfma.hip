@@ -269,7 +269,8 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     // arithmetic runs on the scalar unit and the loads use the saddr form -- vector instructions in the tap loop
     // compete with the MFMAs for issue, scalar ones do not.
     const unsigned a_lane = BF16 ? (unsigned)((lhi * p.cout_p + l31) * (SPLIT ? 32 : 16))
-                                 : (unsigned)((lhi * p.cout_p + l31) * 4);
+                            : (WM == 2 && WN == 2) ? (unsigned)((lhi * p.cout_p + l31) * 32)
+                                                   : (unsigned)((lhi * p.cout_p + l31) * 4);
     auto load_a = [&](int m0, int ci0, int tap, ASet& a) {
         if constexpr (BF16) {
             constexpr int FB = SPLIT ? 32 : 16;                // bytes per (row, k-half): hi | lo fragments, or one
@@ -278,6 +279,18 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
             if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65]; }
             else { a.q[0] = wp[0]; a.q[1] = wp[32]; }
+        } else if constexpr (WM == 2 && WN == 2) {
+            // fragment image: the lane's 8 k-step values of a row are 32 contiguous bytes -- 4 x 16-byte loads per
+            // tap instead of 16 dword loads
+            const char* base = reinterpret_cast<const char*>(p.wf) +
+                               ((long)((tap * ntiles + ci0 / KC) * 2) * p.cout_p + m0) * 32;
+            const float4* wp = reinterpret_cast<const float4*>(base + a_lane);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float4 u = wp[64 * mi], v = wp[64 * mi + 1];
+                a.f[0][mi] = u.x; a.f[1][mi] = u.y; a.f[2][mi] = u.z; a.f[3][mi] = u.w;
+                a.f[4][mi] = v.x; a.f[5][mi] = v.y; a.f[6][mi] = v.z; a.f[7][mi] = v.w;
+            }
         } else {
             const char* base = reinterpret_cast<const char*>(p.w) + ((long)(tap * p.cin_p + ci0) * p.cout_p + m0) * 4;
 #pragma unroll

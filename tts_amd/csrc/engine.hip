@@ -97,6 +97,7 @@ struct ConvW {
     float* w = nullptr; float* bias = nullptr;
     uint16_t* wb = nullptr;            // bf16 image for the bf16 MFMA mode (2x2 tile shape only)
     uint16_t* wb2 = nullptr;           // split (hi | lo) bf16 image for the bf16x3 mode
+    float* wf = nullptr;               // fp32 fragment image (2x2 tile shape): two 16-byte loads per lane, row and tap
     int cin = 0, cin_p = 0, cout = 0, cout_p = 0, taps = 0, pad = 0;
     unsigned* tapmask = nullptr; int up_s = 0, up_shift = 0;
 };
@@ -198,6 +199,20 @@ struct k82_handle {
         HIPCHK(hipMemcpy(d, o.data(), o.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         return d;
     }
+    // fp32 fragment image: [tap][cin_p/16][k-half][cout_p][8], element j = t[tap][16 it + 2 j + half][co]
+    float* upload_frag(const std::vector<float>& t, int taps, int cin_p, int cout_p) {
+        if (cout_p % 128 != 0) return nullptr;
+        const int nt = cin_p / 16;
+        std::vector<float> o((size_t)taps * cin_p * cout_p);
+        for (int kk = 0; kk < taps; ++kk)
+            for (int it = 0; it < nt; ++it)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int co = 0; co < cout_p; ++co)
+                        for (int j = 0; j < 8; ++j)
+                            o[((((size_t)kk * nt + it) * 2 + hh) * cout_p + co) * 8 + j] =
+                                t[((size_t)kk * cin_p + it * 16 + 2 * j + hh) * cout_p + co];
+        return upload(o);
+    }
     // split image for the bf16x3 mode: [tap][cin_p/16][k-half][cout_p][hi 8 | lo 8], w ~= hi + lo to 2^-17 relative
     uint16_t* upload_split(const std::vector<float>& t, int taps, int cin_p, int cout_p) {
         if (cout_p % 128 != 0) return nullptr;
@@ -286,6 +301,7 @@ struct k82_handle {
         c.w = upload(t);
         c.wb = upload_bf16(t, k, c.cin_p, c.cout_p);
         c.wb2 = upload_split(t, k, c.cin_p, c.cout_p);
+        c.wf = upload_frag(t, k, c.cin_p, c.cout_p);
         std::vector<float> bp(c.cout_p, 0.f);        // always present, padded to cout_p (the kernel loads it unconditionally)
         if (bias) std::copy(bias->begin(), bias->end(), bp.begin());
         c.bias = upload(bp);
@@ -325,6 +341,7 @@ struct k82_handle {
         c.w = upload(t);
         c.wb = upload_bf16(t, 3, c.cin_p, c.cout_p);
         c.wb2 = upload_split(t, 3, c.cin_p, c.cout_p);
+        c.wf = upload_frag(t, 3, c.cin_p, c.cout_p);
         c.bias = upload(bp);
         std::vector<unsigned> mask(c.cout_p / 64, 0x7u);
         for (size_t mt = 0; mt < mask.size(); ++mt) {
@@ -507,7 +524,7 @@ struct k82_handle {
         ConvP p;
         std::memset(&p, 0, sizeof(p));
         p.x = x; p.xbs = xbs; p.xpitch = xpitch;
-        p.w = w.w; p.bias = w.bias;
+        p.w = w.w; p.bias = w.bias; p.wf = w.wf;
         p.wb = bf16_now ? (precision == 2 ? w.wb2 : w.wb) : nullptr;
         p.wb_split = bf16_now && precision == 2 && w.wb2;
         p.y = y; p.ybs = ybs; p.ypitch = ypitch;
@@ -524,6 +541,7 @@ struct k82_handle {
     static void check_conv(const ConvP& p) {
         REQUIRE((p.taps - 1) * p.dil <= 64, K82_EINVAL, "conv halo exceeds the LDS tile");
         REQUIRE(p.x && p.w && p.bias && (p.y || p.accbuf), K82_EINVAL, "conv operand missing");
+        REQUIRE(p.cout_p % 128 != 0 || p.wf, K82_EINVAL, "conv fragment image missing");
         REQUIRE(p.cin_p % 16 == 0 && p.cout_p % 64 == 0 && p.cin <= p.cin_p && p.cout <= p.cout_p, K82_EINVAL, "conv channel padding");
         REQUIRE(p.xpitch % 4 == 0 && (!p.y || p.ypitch % 4 == 0) && (!p.res || p.res_shift || p.up_s || p.rpitch % 4 == 0) &&
                 (!p.accbuf || p.apitch % 4 == 0), K82_EINVAL, "conv row pitch must be a multiple of 4 floats");

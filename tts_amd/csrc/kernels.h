@@ -26,6 +26,9 @@ struct ConvP {
     const float* w;                            // weights [taps][cin_p][cout_p] (tap-major, cout contiguous)
     const uint16_t* wb;                        // bf16 image of the same weights (nullptr: fp32 MFMA):
                                                // [taps][cin_p/16][2 k-halves][cout_p][8], 16 B per (row, k-half)
+    const float* wf;                           // fp32 fragment image [taps][cin_p/16][2 k-halves][cout_p][8]: element j is
+                                               // w[tap][16 it + 2 j + half][co], the 8 A values a lane feeds to the 8
+                                               // fp32 MFMA k-steps of a ci-tile, 32 contiguous bytes (nullptr: 1x4 shape)
     int wb_split;                              // 1: wb is the split image [..][cout_p][hi 8 | lo 8] (32 B per row and
                                                // k-half), hi = rne_bf16(w), lo = rne_bf16(w - hi): the bf16x3 mode
     const float* bias;                         // [cout_p] or nullptr
