@@ -104,6 +104,24 @@ enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
 // epilogue), so that every SIMD always pairs a matrix-bound wave with a VALU-bound one.  Correct, but 5-10 % slower
 // in the split mode and 20-35 % slower in the bf16 mode than two free-running 256-thread workgroups: a lone wave's
 // tap step is bound by its own in-order issue -- weight loads, LDS reads, waits, 12 MFMAs -- not by the partner.)
+// Two elements at a time on the packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: IEEE-identical to the
+// scalar forms, half the issue slots -- every vector instruction of the staging step is one the partner wave's
+// MFMAs have to share the SIMD's issue with).
+__device__ __forceinline__ floatx2 fma2(floatx2 a, floatx2 b, floatx2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {          // == snake() per element
+    const floatx2 x = v * al;
+    floatx2 k = x * 0.318309886183790672f;
+    k.x = rintf(k.x); k.y = rintf(k.y);
+    floatx2 r = fma2(-k, (floatx2)(3.140625f), x);
+    r = fma2(-k, (floatx2)(9.67653589793e-4f), r);
+    const floatx2 r2 = r * r;
+    floatx2 pl = fma2(r2, (floatx2)(-2.50521083854e-8f), (floatx2)(2.75573192240e-6f));
+    pl = fma2(r2, pl, (floatx2)(-1.98412698413e-4f));
+    pl = fma2(r2, pl, (floatx2)(8.33333333333e-3f));
+    pl = fma2(r2, pl, (floatx2)(-1.66666666667e-1f));
+    const floatx2 sn = fma2(r * r2, pl, r);
+    return fma2((floatx2)(ial), sn * sn, v);
+}
 template <int WM, int WN, int EPI, bool SNAKE, int PREC>
 __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
@@ -216,13 +234,27 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 const unsigned t = (unsigned)(T.tbase + 4 * (lane + 64 * k));
-                const float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
+                if constexpr (!BF16) {
+                    // fp32 mode: two elements per packed instruction (measured: Snake convs +2..10 %; in the bf16
+                    // modes the register pairs get in the way of the split / pack step: -5..15 %, scalar form kept)
+                    const floatx2 v2[2] = {{raw[cc][k].x, raw[cc][k].y}, {raw[cc][k].z, raw[cc][k].w}};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float u = fmaf(v[e], sc, of);
-                    if constexpr (SNAKE) u = BF16 ? snake_fast(u, alr[cc], ialr[cc]) : snake(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
-                    else u = fmaxf(u, u * slope);
-                    out[cc][k][e] = (t + e < lin) ? u : 0.f;          // t < 0 wraps to a huge unsigned: also invalid
+                    for (int h = 0; h < 2; ++h) {
+                        floatx2 u = fma2(v2[h], (floatx2)(sc), (floatx2)(of));
+                        if constexpr (SNAKE) u = snake2(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
+                        else { const floatx2 w = u * slope; u.x = fmaxf(u.x, w.x); u.y = fmaxf(u.y, w.y); }
+                        out[cc][k][2 * h] = (t + 2 * h < lin) ? u.x : 0.f;      // t < 0 wraps to a huge unsigned: also invalid
+                        out[cc][k][2 * h + 1] = (t + 2 * h + 1 < lin) ? u.y : 0.f;
+                    }
+                } else {
+                    const float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = fmaf(v[e], sc, of);
+                        if constexpr (SNAKE) u = snake_fast(u, alr[cc], ialr[cc]);
+                        else u = fmaxf(u, u * slope);
+                        out[cc][k][e] = (t + e < lin) ? u : 0.f;
+                    }
                 }
             }
         }
