@@ -127,11 +127,12 @@ def main():
         # HBM bytes per launch of the dominant kernel family come from the committed rocprofv3 PMC passes of this
         # same command (counters cannot be read from inside the process); see profiles/*_traffic.json.
         traffic, traffic_src = None, None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v2_traffic.json")
-        if os.path.exists(tp) and B == 64 and T == 256 and not bf16:
+        tname = {"fp32": "r01_v6_traffic.json", "bf16x3": "r01_v6_traffic_bf16x3.json"}.get(args.dtype)
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname or "")
+        if tname and os.path.exists(tp) and B == 64 and T == 256:
             with open(tp) as fh:
                 traffic = json.load(fh)["conv_mfma_2x2_family"]["traffic_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_v2_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes"
+            traffic_src = f"profiles/{tname}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes (tools/make_traffic.py)"
         out = {
             "metric": "audio-sec synthesized/sec (node) Kokoro-82M",
             "value": audio_all * args.steps / dt,
