@@ -26,6 +26,9 @@
 #ifndef K82_OCC_BF16
 #define K82_OCC_BF16 3              // workgroups per CU (= waves per SIMD) the bf16-mode kernels are built for
 #endif
+#ifndef K82_SMALL_GRID
+#define K82_SMALL_GRID 128          // fp32 launches with fewer 128 x 128 output tiles than this use 64 x 64 tiles
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -122,11 +125,16 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
     const floatx2 sn = fma2(r * r2, pl, r);
     return fma2((floatx2)(ial), sn * sn, v);
 }
-template <int WM, int WN, int EPI, bool SNAKE, int PREC>
+// HT: a wave owns HT x HT MFMA tiles (HT = 2: 64 x 64, the throughput shape; HT = 1: 32 x 32, four times as many
+// output tiles for launches that would otherwise occupy a fraction of the CUs -- single sentences, token-rate
+// layers; same K order per output element, so the results are bit-identical to the HT = 2 kernel's).
+template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC>
 __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
-    constexpr int BM = 64 * WM, BN = 64 * WN, KC = 16, WP = BN + 68, NW = WM * WN;
+    constexpr int WT = 32 * HT;                    // rows and columns of a wave's output tile
+    constexpr int BM = WT * WM, BN = WT * WN, KC = 16, WP = BN + 68, NW = WM * WN;
+    static_assert(HT == 2 || (HT == 1 && !BF16), "the 32 x 32 wave tile is an fp32 shape");
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
     constexpr int PATCH = 32 * 36 + 64;        // per-wave epilogue patch [32][36] + the wave's 64 bias values
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: Tile stays in SGPRs
     const int wm = wave / WN, wn = wave % WN;
-    const int nw = wn * 64;
+    const int nw = wn * WT;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ntiles = p.cin_p / KC;
     const int MT = p.cout_p / BM, NT = (p.Lmax_out + BN - 1) / BN;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         T.Lin = p.lin.len(T.b);
         T.Lout = p.lout.len(T.b);
         if (T.n0 >= T.Lout) return false;
-        T.m0 = mt * BM + wm * 64;
+        T.m0 = mt * BM + wm * WT;
         // the LDS tile starts at the 16-byte aligned position tbase <= n0 - pad: every global load is
         // an aligned float4 (rows are 16-B aligned, pitch % 4 == 0), every LDS write a ds_write_b128
         T.tbase = ((T.n0 - p.pad) >> 2) << 2;
@@ -174,12 +182,12 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         return -1;
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[HT][HT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < HT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < HT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
@@ -311,14 +319,14 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
             if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65]; }
             else { a.q[0] = wp[0]; a.q[1] = wp[32]; }
-        } else if constexpr (WM == 2 && WN == 2) {
+        } else if constexpr (WM == 2 && WN == 2) {              // (both wave-tile sizes)
             // fragment image: the lane's 8 k-step values of a row are 32 contiguous bytes -- 4 x 16-byte loads per
             // tap instead of 16 dword loads
             const char* base = reinterpret_cast<const char*>(p.wf) +
                                ((long)((tap * ntiles + ci0 / KC) * 2) * p.cout_p + m0) * 32;
             const float4* wp = reinterpret_cast<const float4*>(base + a_lane);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < HT; ++mi) {
                 const float4 u = wp[64 * mi], v = wp[64 * mi + 1];
                 a.f[0][mi] = u.x; a.f[1][mi] = u.y; a.f[2][mi] = u.z; a.f[3][mi] = u.w;
                 a.f[4][mi] = v.x; a.f[5][mi] = v.y; a.f[6][mi] = v.z; a.f[7][mi] = v.w;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             for (int kk = 0; kk < KC / 2; ++kk) {
                 const float* wp = reinterpret_cast<const float*>(base + (long)(2 * kk) * p.cout_p * 4 + a_lane);
                 a.f[kk][0] = wp[0];
-                a.f[kk][1] = wp[32];
+                if constexpr (HT == 2) a.f[kk][1] = wp[32];
             }
         }
     };
@@ -381,11 +389,13 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
                 const float b0 = xsp[2 * kk * WP];
-                const float b1 = xsp[2 * kk * WP + 32];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b1, acc[1][1], 0, 0, 0);
+                if constexpr (HT == 2) {
+                    const float b1 = xsp[2 * kk * WP + 32];
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b1, acc[1][1], 0, 0, 0);
+                }
             }
         }
     };
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             const int tl = ((T.Lout - 1) >> 2) << 2;
             float4 r4[2][4], a4[2][4];
             auto issue = [&](int idx, float4 (&r)[4], float4 (&a)[4]) {
-                const int mi = idx >> 1, ni = idx & 1;
+                const int mi = idx / HT, ni = idx % HT;
                 const int tc = min(T.n0 + nw + ni * 32 + c4, tl);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -419,9 +429,9 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             };
             issue(0, r4[0], a4[0]);
 #pragma unroll
-            for (int idx = 0; idx < 4; ++idx) {
-                const int mi = idx >> 1, ni = idx & 1;
-                if (idx + 1 < 4) issue(idx + 1, r4[(idx + 1) & 1], a4[(idx + 1) & 1]);
+            for (int idx = 0; idx < HT * HT; ++idx) {
+                const int mi = idx / HT, ni = idx % HT;
+                if (idx + 1 < HT * HT) issue(idx + 1, r4[(idx + 1) & 1], a4[(idx + 1) & 1]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
                 const int t = T.n0 + nw + ni * 32 + c4;
@@ -461,9 +471,9 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             const int rpitch = p.res ? p.rpitch : 0;
             const float rmul = p.res ? 1.f : 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < HT; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < HT; ++ni) {
                     const int t = T.n0 + nw + ni * 32 + l31;
                     const int tc = min(t, T.Lout - 1);
                     float rv[16];
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         const int qn = next_valid(q + G, nxt);
         const bool have_next = qn >= 0;
         if (!have_next) nxt = cur;
-        const float bias_l = p.bias[cur.m0 + lane];          // bias is padded to cout_p; lands during the main loop
+        const float bias_l = p.bias[min(cur.m0 + lane, p.cout_p - 1)];   // bias is padded to cout_p; lands during the main loop
         zero_acc();
         int tap = cur.tap0;
         auto next_tap = [&](int t) -> int {
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
 #pragma unroll
                         for (int kk = 0; kk < KC / 2; ++kk) {
                             asm volatile("v_mov_b32 %0, %1" : "=v"(a0.f[kk][0]) : "v"(a1.f[kk][0]));
-                            asm volatile("v_mov_b32 %0, %1" : "=v"(a0.f[kk][1]) : "v"(a1.f[kk][1]));
+                            if constexpr (HT == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(a0.f[kk][1]) : "v"(a1.f[kk][1]));
                         }
                     }
                 }
@@ -608,19 +618,19 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     }
 }
 
-template <int WM, int WN, bool SNAKE, int BF16>
+template <int WM, int WN, bool SNAKE, int BF16, int HT = 2>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     switch (epi) {
-    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_PLAIN, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_RES, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_ACC, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
-    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, EPI_SCALAR, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
     }
 }
-template <int WM, int WN>
+template <int WM, int WN, int HT = 2>
 static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
-    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32>(p, epi, grid, s);
-    else launch_epi<WM, WN, false, PREC_F32>(p, epi, grid, s);
+    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT>(p, epi, grid, s);
+    else launch_epi<WM, WN, false, PREC_F32, HT>(p, epi, grid, s);
 }
 static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {       // 2x2 shape only
     const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
@@ -644,7 +654,11 @@ void launch_conv(const ConvP& p, hipStream_t s) {
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
         if (p.wb) launch_bf16(p, epi, total, s);
-        else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
+        else if (total < K82_SMALL_GRID) {
+            // too few 128 x 128 tiles to occupy the chip: 64 x 64 tiles (32 x 32 per wave), four times as many
+            const long t64 = (long)((p.Lmax_out + 63) / 64) * (p.cout_p / 64) * p.B;
+            launch_shape<2, 2, 1>(p, epi, (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks), s);
+        } else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
         launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
