@@ -27,7 +27,7 @@
 #define K82_OCC_BF16 3              // workgroups per CU (= waves per SIMD) the bf16-mode kernels are built for
 #endif
 #ifndef K82_SMALL_GRID
-#define K82_SMALL_GRID 128          // fp32 launches with fewer 128 x 128 output tiles than this use 64 x 64 tiles
+#define K82_SMALL_GRID 512          // fp32 launches whose 128 x 128 tiles would not fill the persistent grid use 64 x 64 tiles
 #endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
