@@ -481,3 +481,24 @@ def test_bf16x3_waveform_meets_fp32_bar(engine, oracle_model):
     finally:
         engine.set_precision("fp32")
         engine.debug_enable(False)
+
+
+@pytest.mark.gpu
+def test_sentence_is_bit_identical_alone_and_in_a_large_batch(engine):
+    """Small launches take different kernels than large ones (32 x 32 instead of 64 x 64 wave tiles in the fp32 conv,
+    the four-workgroup weight-resident LSTM instead of the streaming one for B <= 16): both pairs are written to
+    perform the same arithmetic in the same order, so a sentence must synthesize to the same durations and the same
+    samples, bit for bit, alone and inside a batch of 40 (the reference synthesizes one sentence per call)."""
+    lengths = [37, 90, 12] + [60 + (7 * i) % 50 for i in range(37)]
+    id_lists, ref_s = H.make_batch(21, lengths)
+    ids, lens = engine.pack(id_lists)
+    pred_b, nfr_b = engine.durations(ids, lens, ref_s)
+    noise_b = _noise_for(nfr_b)
+    audio_b, off_b = engine.decode(noise=noise_b)
+    audio_b = audio_b.copy()
+    for k in range(3):
+        i1, l1 = engine.pack([id_lists[k]])
+        pred_1, nfr_1 = engine.durations(i1, l1, ref_s[k:k + 1])
+        assert np.array_equal(pred_1[0, :l1[0]], pred_b[k, :lens[k]])
+        a1, off1 = engine.decode(noise=noise_b.reshape(-1, 9)[off_b[k]:off_b[k + 1]].reshape(-1))
+        assert np.array_equal(a1, audio_b[off_b[k]:off_b[k + 1]]), float(np.abs(a1 - audio_b[off_b[k]:off_b[k + 1]]).max())

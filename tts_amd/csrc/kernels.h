@@ -78,6 +78,9 @@ void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long c
 // BiLSTM recurrence, hidden 256.  gx [B][2048][pitch] (fwd gates i,f,g,o then reverse), whh [2][256(k)][256(j)][4]
 void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch,
                  LenSpec ls, int B, hipStream_t s);
+void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
+                       int B, float* hx, int* flags, int* err, hipStream_t s);
+#define K82_LSTM_SPLIT_MAX_B 16     // 8 workgroups per sentence, one per CU: all resident at once on 256 CUs
 // rows [r0, r0+n) of y get value v[b*vstride + voff + i] for t < L_b (style broadcast)
 void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
                       LenSpec ls, int B, int Tmax, hipStream_t s);

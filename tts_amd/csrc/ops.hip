@@ -366,9 +366,100 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, i
         p ^= 1;
     }
 }
+// Small batches (single sentences): one (direction, sentence) recurrence spread over FOUR workgroups, 64 hidden units
+// each, with the unit's W_hh rows RESIDENT IN REGISTERS (thread = k-quarter x unit x gate pair: 64 k x 2 gates = 128
+// VGPRs) instead of 1 MB streamed from L2 through one CU every step (7.8 us at 64 B/clk -- the step time of the
+// kernel above when only two workgroups run).  Per step each workgroup publishes its 64 new h values in global memory
+// and waits for the other three (device-scope flags, bounded spin).  Arithmetic is IDENTICAL to lstm_kernel's: the
+// same four k-quarter chains per gate in the same order, the same partial-sum tree, the same gate code -- a sentence
+// gives the same bits alone (this kernel) and in a large batch (that kernel).
+// Co-residency: the four parts of a recurrence are adjacent in dispatch order and the launcher uses this kernel only
+// when every workgroup of the grid fits on the chip at once (one 512-thread, 256-VGPR workgroup per CU); a spin that
+// exceeds its bound sets *err and every wave leaves its loop.
+__global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
+                                                           long ybs, int ypitch, LenSpec ls, float* hx, int* flags, int* err) {
+    __shared__ __attribute__((aligned(16))) float hbuf[256];
+    __shared__ float2 part[4][2][64];
+    __shared__ int dead;
+    const int P = blockIdx.x & 3, dir = (blockIdx.x >> 2) & 1, b = blockIdx.x >> 3;
+    const int tid = threadIdx.x, pt = tid >> 7, g2 = (tid >> 6) & 1, jl = tid & 63, j = 64 * P + jl;
+    const int T = ls.len(b);
+    float2 w[64];
+    {
+        const float4* W = reinterpret_cast<const float4*>(whh) + (long)dir * 256 * 256 + (long)(64 * pt) * 256 + j;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) w[k] = reinterpret_cast<const float2*>(W + (long)k * 256)[g2];
+    }
+    const float* g0 = gx + (long)b * gbs + (long)(dir * 1024 + j) * gpitch;
+    const long gs = (long)256 * gpitch;
+    float* yo = y + (long)b * ybs + (long)(dir * 256 + j) * ypitch;
+    float* H = hx + (long)(b * 2 + dir) * 512;
+    int* F = flags + (b * 2 + dir) * 4;
+    float c = 0.f;
+    if (tid < 256) hbuf[tid] = 0.f;
+    if (tid == 0) dead = 0;
+    float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 64 && T > 0) {
+        const int t0 = dir ? T - 1 : 0;
+        gn = make_float4(g0[t0], g0[gs + t0], g0[2 * gs + t0], g0[3 * gs + t0]);
+    }
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        const float4 gcur = gn;
+        if (tid < 64 && s + 1 < T) {
+            const int tn = dir ? t - 1 : t + 1;
+            gn = make_float4(g0[tn], g0[gs + tn], g0[2 * gs + tn], g0[3 * gs + tn]);
+        }
+        float a0 = 0.f, a1 = 0.f;
+        const float4* h4 = reinterpret_cast<const float4*>(hbuf) + 16 * pt;
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const float4 hv = h4[k4];
+            a0 += w[4 * k4 + 0].x * hv.x; a1 += w[4 * k4 + 0].y * hv.x;
+            a0 += w[4 * k4 + 1].x * hv.y; a1 += w[4 * k4 + 1].y * hv.y;
+            a0 += w[4 * k4 + 2].x * hv.z; a1 += w[4 * k4 + 2].y * hv.z;
+            a0 += w[4 * k4 + 3].x * hv.w; a1 += w[4 * k4 + 3].y * hv.w;
+        }
+        part[pt][g2][jl] = make_float2(a0, a1);
+        __syncthreads();
+        if (tid < 64) {
+            const float2 i0 = part[0][0][jl], i1 = part[1][0][jl], i2 = part[2][0][jl], i3 = part[3][0][jl];
+            const float2 o0 = part[0][1][jl], o1 = part[1][1][jl], o2 = part[2][1][jl], o3 = part[3][1][jl];
+            const float ai = gcur.x + ((i0.x + i1.x) + (i2.x + i3.x));
+            const float af = gcur.y + ((i0.y + i1.y) + (i2.y + i3.y));
+            const float ag = gcur.z + ((o0.x + o1.x) + (o2.x + o3.x));
+            const float ao = gcur.w + ((o0.y + o1.y) + (o2.y + o3.y));
+            const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanhf(ag), og = sigmoidf_(ao);
+            c = fg * c + ig * gg;
+            const float hn = og * tanhf(c);
+            yo[t] = hn;
+            __hip_atomic_store(&H[(s & 1) * 256 + j], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            if (tid == 0) __hip_atomic_store(&F[P], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 4) {
+                int spins = 0;
+                while (__hip_atomic_load(&F[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < s + 1) {
+                    if (++spins > (1 << 20)) { dead = 1; *err = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        __syncthreads();
+        if (dead) break;
+        if (tid < 256) hbuf[tid] = __hip_atomic_load(&H[(s & 1) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+}
 void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
                  int B, hipStream_t s) {
     hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(1024), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
+}
+// hx: float[B][2][2][256] exchange buffer, flags: int[B][2][4] zeroed here, err: one device int (sticky)
+void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
+                       int B, float* hx, int* flags, int* err, hipStream_t s) {
+    (void)hipMemsetAsync(flags, 0, (size_t)B * 8 * sizeof(int), s);
+    hipLaunchKernelGGL(lstm_split_kernel, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, hx, flags, err);
 }
 
 // ------------------------------------------------------------------------ small helpers
