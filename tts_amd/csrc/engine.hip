@@ -149,6 +149,7 @@ struct k82_handle {
     bool have_phase1 = false;
     int* lstm_err = nullptr;           // device word: set by lstm_split_kernel if a cross-workgroup wait ran out
     int lstm_err_h = 0;
+    int lstm_split_max_b = 0;          // CUs / 8, set in finalize()
     void check_lstm() {                // at points where the stream has just been synchronised
         HIPCHK(hipMemcpy(&lstm_err_h, lstm_err, sizeof(int), hipMemcpyDeviceToHost));
         REQUIRE(lstm_err_h == 0, K82_EHIP, "LSTM recurrence: a workgroup waited too long for its partners (results invalid)");
@@ -520,6 +521,11 @@ struct k82_handle {
         conv_post = mk_conv(G + ".conv_post", 22, 128, 7);
         sfc_pros_w = upload(sp.W); sfc_pros_b = upload(sp.b); Gp = sp.rows;
         sfc_dec_w = upload(sd.W); sfc_dec_b = upload(sd.b); Gd = sd.rows;
+        {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, device));
+            lstm_split_max_b = prop.multiProcessorCount / 8;
+        }
         lstm_err = (int*)wmalloc(sizeof(int));
         HIPCHK(hipMemset(lstm_err, 0, sizeof(int)));
         host.clear();
@@ -638,7 +644,7 @@ struct k82_handle {
         float* gx = ar.f((size_t)B * 2048 * gp);
         ConvP p = cp(L.ih, x, xbs, xpitch, gx, (long)2048 * gp, gp, ls, ls, B, Lmax);
         run_conv(p, hbase);
-        if (B <= K82_LSTM_SPLIT_MAX_B) {      // few sentences: the weight-resident four-workgroup recurrence (same bits)
+        if (B <= lstm_split_max_b) {      // few sentences: the weight-resident four-workgroup recurrence (same bits)
             float* hx = ar.f((size_t)B * 1024);
             int* flags = (int*)ar.alloc((size_t)B * 8 * sizeof(int));
             timed(FAM_LSTM, steps, [&] { launch_lstm_split(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, hx, flags, lstm_err, st); });
@@ -754,7 +760,7 @@ struct k82_handle {
             HIPCHK(hipMemcpyAsync(dur_h.data(), dur_d, dur_h.size() * sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
         }
-        if (B <= K82_LSTM_SPLIT_MAX_B) check_lstm();
+        if (B <= lstm_split_max_b) check_lstm();
         if (pred_dur) std::copy(dur_h.begin(), dur_h.end(), pred_dur);
         if (n_frames)
             for (int b = 0; b < nb; ++b) {
@@ -939,7 +945,7 @@ struct k82_handle {
         if (!on_dev) HIPCHK(hipMemcpyAsync(audio, adev, (size_t)aoff[nb] * sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
-        if (nb <= K82_LSTM_SPLIT_MAX_B) check_lstm();
+        if (nb <= lstm_split_max_b) check_lstm();
     }
 };
 

@@ -80,7 +80,9 @@ void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float*
                  LenSpec ls, int B, hipStream_t s);
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
                        int B, float* hx, int* flags, int* err, hipStream_t s);
-#define K82_LSTM_SPLIT_MAX_B 16     // 8 workgroups per sentence, one per CU: all resident at once on 256 CUs
+// the split recurrence needs every workgroup of its grid resident at once (8 per sentence, one per CU): the engine
+// uses it for B <= CUs / 8 (32 on MI355X); beyond that the grid runs in rounds and the streaming kernel is faster
+// (measured at B = 64: 89 ms vs 39 ms per configs[1] step)
 // rows [r0, r0+n) of y get value v[b*vstride + voff + i] for t < L_b (style broadcast)
 void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
                       LenSpec ls, int B, int Tmax, hipStream_t s);
