@@ -227,73 +227,91 @@ void launch_embed(const int64_t* ids, int Tmax, const float* emb, int C, float* 
 }
 
 // ------------------------------------------------------------------ attention (row a5)
-// One wave per (64 queries, head, sentence); lane = query.  K/V tiles of 64 keys go through
-// LDS ([d][key], rows coalesced from the channel-first qkv tensor); every lane reads the same
-// LDS word per (d, key) step => broadcast, no bank conflict.  Online softmax per 64-key tile.
+// One wave per (32 queries, head, sentence) on v_mfma_f32_32x32x2_f32 (exact fp32), flash style over 32-key tiles:
+//   S^T = K Q^T   (rows = keys, columns = queries): A = K[key][d] straight from the channel-first qkv tensor (lane =
+//                  key: coalesced rows), B = the lane's 32 pre-scaled Q values (lane = query), 32 MFMAs
+//   online softmax per COLUMN: a lane and its partner (lane ^ 32) hold the 32 keys of one query -- the running
+//                  max / sum / rescale are lane-local plus one cross-half exchange, no LDS
+//   O^T += V^T P^T (rows = d, columns = queries): the B operand of k-step s is the lane's OWN P register s -- the
+//                  step simply consumes the key that register holds (key order inside a tile does not matter to the
+//                  sum) -- and A = V[d][that key] from the V tile staged in LDS ([d][33]: conflict-free), 32 MFMAs
+// so no score or probability ever moves between lanes.  (The first version, one query per lane with 64 x 64 scalar
+// FMAs per key tile, spent 15 ms per configs[1] step and 160 us per launch on a single sentence.)
+typedef float attn_f16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, long qbs, int qpitch, float* ctx, long cbs,
                                                       int cpitch, LenSpec ls, int heads) {
-    __shared__ float Ks[64 * 64];
-    __shared__ float Vs[64 * 64];
-    const int b = blockIdx.z, hd = blockIdx.y, lane = threadIdx.x;
+    __shared__ float Vs[64 * 33];
+    const int b = blockIdx.z, hd = blockIdx.y, lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
     const int T = ls.len(b);
-    const int q0 = blockIdx.x * 64;
+    const int q0 = blockIdx.x * 32;
     if (q0 >= T) return;
-    const int tq = q0 + lane;
     const int HD = heads * 64;
     const float* qb = qkv + (long)b * qbs + (long)(hd * 64) * qpitch;
     const float* kb = qb + (long)HD * qpitch;
     const float* vb = kb + (long)HD * qpitch;
-    float q[64], o[64];
-    const int tql = tq < T ? tq : T - 1;
+    const int tq = min(q0 + l31, T - 1);
+    float qf[32];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-        q[d] = qb[(long)d * qpitch + tql] * 0.125f;
-        o[d] = 0.f;
-    }
+    for (int s = 0; s < 32; ++s) qf[s] = qb[(long)(2 * s + lhi) * qpitch + tq] * 0.125f;
+    attn_f16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -1e30f, l = 0.f;
-    for (int j0 = 0; j0 < T; j0 += 64) {
-        __syncthreads();
-        const int jj = j0 + lane;
-        for (int d = 0; d < 64; ++d) {
-            Ks[d * 64 + lane] = jj < T ? kb[(long)d * qpitch + jj] : 0.f;
-            Vs[d * 64 + lane] = jj < T ? vb[(long)d * qpitch + jj] : 0.f;
-        }
-        __syncthreads();
-        const int nk = min(64, T - j0);
-        float sc[64];
-        float tmax = -1e30f;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        const int kk = min(j0 + l31, T - 1);
+        __syncthreads();                                   // the previous tile's V reads are done
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) Vs[(lhi * 32 + i) * 33 + l31] = vb[(long)(lhi * 32 + i) * qpitch + kk];
+        attn_f16 sacc;
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            float a = 0.f;
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s)
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[(long)(2 * s + lhi) * qpitch + kk], qf[s], sacc, 0, 0, 0);
+        float pv[16], tmax = -1e30f;
 #pragma unroll
-            for (int d = 0; d < 64; ++d) a += q[d] * Ks[d * 64 + j];
-            sc[j] = j < nk ? a : -1e30f;
-            tmax = fmaxf(tmax, sc[j]);
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            pv[r] = key < T ? sacc[r] : -1e30f;
+            tmax = fmaxf(tmax, pv[r]);
         }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mn = fmaxf(m, tmax);
         const float corr = expf(m - mn);
-        l *= corr;
+        float psum = 0.f;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) o[d] *= corr;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const float pj = j < nk ? expf(sc[j] - mn) : 0.f;
-            l += pj;
-#pragma unroll
-            for (int d = 0; d < 64; ++d) o[d] += pj * Vs[d * 64 + j];
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            pv[r] = key < T ? expf(pv[r] - mn) : 0.f;
+            psum += pv[r];
         }
+        psum += __shfl_xor(psum, 32);
+        l = l * corr + psum;
         m = mn;
-    }
-    if (tq < T) {
-        const float inv = 1.0f / l;
-        float* cb = ctx + (long)b * cbs + (long)(hd * 64) * cpitch + tq;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) cb[(long)d * cpitch] = o[d] * inv;
+        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+        __syncthreads();                                   // V tile visible
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int kidx = (s & 3) + 8 * (s >> 2) + 4 * lhi;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[l31 * 33 + kidx], pv[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(32 + l31) * 33 + kidx], pv[s], o1, 0, 0, 0);
+        }
+    }
+    if (q0 + l31 < T) {
+        const float inv = 1.0f / l;
+        float* cb = ctx + (long)b * cbs + (long)(hd * 64) * cpitch + q0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            cb[(long)d * cpitch] = o0[r] * inv;
+            cb[(long)(32 + d) * cpitch] = o1[r] * inv;
+        }
     }
 }
 void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long cbs, int cpitch, LenSpec ls,
                       int heads, int B, int Tmax, hipStream_t s) {
-    hipLaunchKernelGGL(attention_kernel, dim3(DIVUP(Tmax, 64), heads, B), dim3(64), 0, s, qkv, qbs, qpitch, ctx, cbs,
+    hipLaunchKernelGGL(attention_kernel, dim3(DIVUP(Tmax, 32), heads, B), dim3(64), 0, s, qkv, qbs, qpitch, ctx, cbs,
                        cpitch, ls, heads);
 }
 
