@@ -128,12 +128,17 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // HT: a wave owns HT x HT MFMA tiles (HT = 2: 64 x 64, the throughput shape; HT = 1: 32 x 32, four times as many
 // output tiles for launches that would otherwise occupy a fraction of the CUs -- single sentences, token-rate
 // layers; same K order per output element, so the results are bit-identical to the HT = 2 kernel's).
-template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC>
+// KCT: input channels per staged tile.  16 everywhere except the small-launch kernel of 1-tap convolutions (every
+// Linear of the token-rate layers), which takes 32: at 8 MFMAs per tile its K loop is a chain of staging latencies,
+// and twice the channels per barrier halves the chain (1-tap only: with more taps a wider tile would change the
+// order in which an output element's products are summed, and with it the bits).
+template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16>
 __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int WT = 32 * HT;                    // rows and columns of a wave's output tile
-    constexpr int BM = WT * WM, BN = WT * WN, KC = 16, WP = BN + 68, NW = WM * WN;
+    constexpr int BM = WT * WM, BN = WT * WN, KC = KCT, WP = BN + 68, NW = WM * WN;
+    static_assert(KC == 16 || (KC == 32 && HT == 1 && !BF16), "32-channel tiles: small-launch fp32 kernel only");
     static_assert(HT == 2 || (HT == 1 && !BF16), "the 32 x 32 wave tile is an fp32 shape");
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     const int wm = wave / WN, wn = wave % WN;
     const int nw = wn * WT;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int ntiles = p.cin_p / KC;
+    const int ntiles = (p.cin_p + KC - 1) / KC, nt16 = p.cin_p / 16;      // staged tiles; 16-channel tiles of the weight images
     const int MT = p.cout_p / BM, NT = (p.Lmax_out + BN - 1) / BN;
     const int total = MT * NT * p.B, G = gridDim.x;
     const unsigned tapall = (p.taps >= 32) ? 0xffffffffu : ((1u << p.taps) - 1u);
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         if constexpr (BF16) {
             constexpr int FB = SPLIT ? 32 : 16;                // bytes per (row, k-half): hi | lo fragments, or one
             const char* base = reinterpret_cast<const char*>(p.wb) +
-                               ((long)((tap * ntiles + ci0 / KC) * 2) * p.cout_p + m0) * FB;
+                               ((long)((tap * nt16 + ci0 / 16) * 2) * p.cout_p + m0) * FB;
             const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
             if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65]; }
             else { a.q[0] = wp[0]; a.q[1] = wp[32]; }
@@ -323,14 +328,16 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             // fragment image: the lane's 8 k-step values of a row are 32 contiguous bytes -- 4 x 16-byte loads per
             // tap instead of 16 dword loads
             const char* base = reinterpret_cast<const char*>(p.wf) +
-                               ((long)((tap * ntiles + ci0 / KC) * 2) * p.cout_p + m0) * 32;
-            const float4* wp = reinterpret_cast<const float4*>(base + a_lane);
+                               ((long)((tap * nt16 + ci0 / 16) * 2) * p.cout_p + m0) * 32;
 #pragma unroll
-            for (int mi = 0; mi < HT; ++mi) {
-                const float4 u = wp[64 * mi], v = wp[64 * mi + 1];
-                a.f[0][mi] = u.x; a.f[1][mi] = u.y; a.f[2][mi] = u.z; a.f[3][mi] = u.w;
-                a.f[4][mi] = v.x; a.f[5][mi] = v.y; a.f[6][mi] = v.z; a.f[7][mi] = v.w;
-            }
+            for (int h = 0; h < KC / 16; ++h)                   // 16-channel sub-tiles (the image has one spare tile at its end)
+#pragma unroll
+                for (int mi = 0; mi < HT; ++mi) {
+                    const float4* wq = reinterpret_cast<const float4*>(base + (long)h * p.cout_p * 64 + a_lane);
+                    const float4 u = wq[64 * mi], v = wq[64 * mi + 1];
+                    a.f[8 * h + 0][mi] = u.x; a.f[8 * h + 1][mi] = u.y; a.f[8 * h + 2][mi] = u.z; a.f[8 * h + 3][mi] = u.w;
+                    a.f[8 * h + 4][mi] = v.x; a.f[8 * h + 5][mi] = v.y; a.f[8 * h + 6][mi] = v.z; a.f[8 * h + 7][mi] = v.w;
+                }
         } else {
             const char* base = reinterpret_cast<const char*>(p.w) + ((long)(tap * p.cin_p + ci0) * p.cout_p + m0) * 4;
 #pragma unroll
@@ -618,19 +625,19 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     }
 }
 
-template <int WM, int WN, bool SNAKE, int BF16, int HT = 2>
+template <int WM, int WN, bool SNAKE, int BF16, int HT = 2, int KCT = 16>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     switch (epi) {
-    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
-    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
+    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
     }
 }
-template <int WM, int WN, int HT = 2>
+template <int WM, int WN, int HT = 2, int KCT = 16>
 static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
-    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT>(p, epi, grid, s);
-    else launch_epi<WM, WN, false, PREC_F32, HT>(p, epi, grid, s);
+    if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT, KCT>(p, epi, grid, s);
+    else launch_epi<WM, WN, false, PREC_F32, HT, KCT>(p, epi, grid, s);
 }
 static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {       // 2x2 shape only
     const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
@@ -657,7 +664,9 @@ void launch_conv(const ConvP& p, hipStream_t s) {
         else if (total < K82_SMALL_GRID) {
             // too few 128 x 128 tiles to occupy the chip: 64 x 64 tiles (32 x 32 per wave), four times as many
             const long t64 = (long)((p.Lmax_out + 63) / 64) * (p.cout_p / 64) * p.B;
-            launch_shape<2, 2, 1>(p, epi, (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks), s);
+            const unsigned grid = (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks);
+            if (p.taps == 1 && (epi == EPI_PLAIN || epi == EPI_RES)) launch_shape<2, 2, 1, 32>(p, epi, grid, s);
+            else launch_shape<2, 2, 1>(p, epi, grid, s);
         } else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;

@@ -210,7 +210,9 @@ struct k82_handle {
     float* upload_frag(const std::vector<float>& t, int taps, int cin_p, int cout_p) {
         if (cout_p % 128 != 0) return nullptr;
         const int nt = cin_p / 16;
-        std::vector<float> o((size_t)taps * cin_p * cout_p);
+        // one spare all-zero 16-channel tile at the end: the 32-channel small-launch kernel reads a whole pair of tiles
+        // even when cin_p / 16 is odd (the x side of that half-tile is zero)
+        std::vector<float> o((size_t)taps * cin_p * cout_p + (size_t)16 * cout_p, 0.f);
         for (int kk = 0; kk < taps; ++kk)
             for (int it = 0; it < nt; ++it)
                 for (int hh = 0; hh < 2; ++hh)
