@@ -178,3 +178,49 @@ def test_ordered_gather_two_ranks_gloo():
         assert p.exitcode == 0
     counts = [5 + (i * 37) % 200 for i in range(n)]
     assert got == [(i, 600 * (counts[i] % 7 + 1), counts[i]) for i in range(n)]    # strictly by sentence index
+
+
+def _rank_main_pcm(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts = [5 + (i * 37) % 200 for i in range(n)]
+    mine = S.shard_sentences(counts, world)[rank]
+    local = {i: np.full(600 * (counts[i] % 7 + 1), (i - 10) / 20.0, np.float32) for i in mine}      # some clip at +-1
+    res = S.ordered_gather_pcm16(local, n)
+    if rank == 0:
+        q.put([(int(a[0]), int(a[-1]), a.shape[0], str(a.dtype)) for a in res])
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_gather_pcm16_two_ranks_gloo():
+    """The bulk form of the one exchange step: one tensor per rank, 16-bit PCM as the reference plays it
+    (basic.tts_kokoro_2_play_pause_works.py:25), strictly in sentence order on rank 0."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, port = 23, _free_port()
+    procs = [ctx.Process(target=_rank_main_pcm, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts = [5 + (i * 37) % 200 for i in range(n)]
+    want = []
+    for i in range(n):
+        v = int(np.clip(np.float32((i - 10) / 20.0), -1, 1) * np.float32(32767.0))
+        want.append((v, v, 600 * (counts[i] % 7 + 1), "int16"))
+    assert got == want
+
+
+def test_ordered_gather_pcm16_single_process():
+    a = {0: np.array([0.0, 0.5, -2.0], np.float32), 1: np.array([1, 2], np.int16)}
+    out = S.ordered_gather_pcm16(a, 2)
+    assert out[0].tolist() == [0, 16383, -32767] and out[1].tolist() == [1, 2]
+    with pytest.raises(RuntimeError):
+        S.ordered_gather_pcm16({1: np.zeros(3, np.float32)}, 2)

@@ -25,7 +25,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="bf16")      # cfg3 is quoted on the bf16 decoder
 ap.add_argument("--max-batch", type=int, default=256)
 ap.add_argument("--max-sentences", type=int, default=0)
-ap.add_argument("--no-gather", action="store_true", help="skip the final ordered gather of the audio")
+ap.add_argument("--gather", choices=("pcm16", "object", "none"), default="pcm16",
+                help="final ordered gather of the audio to rank 0: one 16-bit PCM tensor per rank over RCCL (default), "
+                     "pickled float32 objects, or none")
 ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                 help="all ranks share GPU 0 and talk over gloo: exercises sharding and the ordered gather on a 1-GPU box")
 args = ap.parse_args()
@@ -45,7 +47,8 @@ red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
 
 from tts_amd import spec, text as T  # noqa: E402
 from tts_amd.engine import Engine  # noqa: E402
-from tts_amd.scheduler import BatchSynthesizer, audio_seconds, ordered_gather, shard_sentences  # noqa: E402
+from tts_amd.scheduler import (BatchSynthesizer, audio_seconds, ordered_gather, ordered_gather_pcm16,  # noqa: E402
+                               shard_sentences)
 
 aow = json.load(gzip.open(os.path.join(ROOT, "tests", "golden", "epub_art_of_war.json.gz")))
 sents = [t for _, t in aow["sentences"]]
@@ -75,7 +78,12 @@ barrier()
 dt = time.perf_counter() - t0
 local_audio = {i: res[i][0] for i in mine}
 t1 = time.perf_counter()
-gathered = None if args.no_gather else ordered_gather(local_audio, len(ids))
+if args.gather == "pcm16":
+    gathered = ordered_gather_pcm16(local_audio, len(ids), device=None if args.rehearse_on_one_gpu else f"cuda:{local}")
+elif args.gather == "object":
+    gathered = ordered_gather(local_audio, len(ids))
+else:
+    gathered = None
 barrier()
 dg = time.perf_counter() - t1
 a_local = audio_seconds(list(local_audio.values()))
@@ -89,7 +97,7 @@ else:
 if rank == 0:
     out = {"config": f"cfg3 ({world} GPU, {args.dtype}): The Art of War, every sentence, sentence-sharded", "n_gpus": world,
            "sentences": len(ids), "tokens": sum(counts), "audio_s": a_all, "wall_s": dt, "audio_s_per_s": a_all / dt,
-           "ordered_gather_s": None if args.no_gather else dg,
+           "ordered_gather": args.gather, "ordered_gather_s": None if args.gather == "none" else dg,
            "gathered_ok": None if gathered is None else bool(len(gathered) == len(ids) and all(g.size > 0 for g in gathered)),
            "phonemes": "surrogate g2p (no phonemizer offline)", "weights": "seeded random",
            "includes": "host packing, H2D ids, D2H audio copies per batch; the final gather is timed separately"}

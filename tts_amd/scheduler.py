@@ -123,5 +123,59 @@ def ordered_gather(local: dict, n_total: int, group=None, dst: int = 0):
     return [merged[i] for i in range(n_total)]
 
 
+def ordered_gather_pcm16(local: dict, n_total: int, group=None, dst: int = 0, device=None):
+    """The same exchange as ``ordered_gather`` for bulk audio, as ONE point-to-point tensor transfer per rank instead
+    of pickled objects: every rank concatenates its sentences as 16-bit PCM (what the reference plays:
+    ``clip(x, -1, 1) * 32767 -> '<i2'``, basic.tts_kokoro_2_play_pause_works.py:25 -- 48 kB per audio-second) in index
+    order, the sample counts travel in one small all_gather, and rank ``dst`` receives each rank's block with
+    ``recv`` (RCCL over xGMI when ``device`` is a CUDA device and the backend is nccl; gloo on CPU tensors otherwise).
+    ``local``: {index: float32 or int16 samples}.  Returns the list of int16 arrays in sentence order on ``dst``,
+    None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from . import wav
+
+    def pcm(a):
+        a = np.asarray(a)
+        return a if a.dtype == np.int16 else wav.f32_to_s16le_array(a)
+
+    idx = sorted(local)
+    blocks = [pcm(local[i]) for i in idx]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if idx != list(range(n_total)):
+            raise RuntimeError("ordered_gather_pcm16: a single rank must hold every sentence")
+        return blocks
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    meta = [None] * world
+    dist.all_gather_object(meta, (idx, [int(b.shape[0]) for b in blocks]), group=group)
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    mine = torch.from_numpy(np.concatenate(blocks) if blocks else np.zeros((0,), np.int16)).to(dev)
+    if rank != dst:
+        if mine.numel():
+            dist.send(mine, dst=dst, group=group)
+        return None
+    out = [None] * n_total
+    for r in range(world):
+        r_idx, r_len = meta[r]
+        total = int(sum(r_len))
+        if r == dst:
+            buf = mine
+        else:
+            buf = torch.empty((total,), dtype=torch.int16, device=dev)
+            if total:
+                dist.recv(buf, src=r, group=group)
+        host = buf.cpu().numpy()
+        pos = 0
+        for i, n in zip(r_idx, r_len):
+            if out[i] is not None:
+                raise RuntimeError(f"ordered_gather_pcm16: sentence {i} was synthesized by two ranks")
+            out[i] = host[pos:pos + n]
+            pos += n
+    missing = [i for i in range(n_total) if out[i] is None]
+    if missing:
+        raise RuntimeError(f"ordered_gather_pcm16: sentences {missing[:5]} were synthesized by no rank")
+    return out
+
+
 def audio_seconds(audios) -> float:
     return sum(a.shape[0] for a in audios) / float(spec.SAMPLE_RATE)

@@ -28,6 +28,12 @@ def f32_to_s16le(x) -> bytes:
     return (np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2").tobytes()
 
 
+def f32_to_s16le_array(x) -> np.ndarray:
+    """The same conversion as ``f32_to_s16le``, as an int16 array."""
+    x = np.asarray(x, dtype=np.float32)
+    return (np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2")
+
+
 def float_to_pcm16_sndfile(x) -> np.ndarray:
     """libsndfile float -> PCM_16 with normalisation and clipping on: lrint(x * 32767) saturated."""
     x = np.asarray(x)
