@@ -485,10 +485,9 @@ def test_bf16x3_waveform_meets_fp32_bar(engine, oracle_model):
 
 @pytest.mark.gpu
 def test_sentence_is_bit_identical_alone_and_in_a_large_batch(engine):
-    """Small launches take different kernels than large ones (32 x 32 instead of 64 x 64 wave tiles in the fp32 conv,
-    the four-workgroup weight-resident LSTM instead of the streaming one for B <= 16): both pairs are written to
-    perform the same arithmetic in the same order, so a sentence must synthesize to the same durations and the same
-    samples, bit for bit, alone and inside a batch of 40 (the reference synthesizes one sentence per call)."""
+    """Small launches take a different conv kernel than large ones (32 x 32 instead of 64 x 64 wave tiles): it is
+    written to perform the same arithmetic in the same order, so a sentence must synthesize to the same durations and
+    the same samples, bit for bit, alone and inside a batch of 40 (the reference synthesizes one sentence per call)."""
     lengths = [37, 90, 12] + [60 + (7 * i) % 50 for i in range(37)]
     id_lists, ref_s = H.make_batch(21, lengths)
     ids, lens = engine.pack(id_lists)
@@ -502,3 +501,28 @@ def test_sentence_is_bit_identical_alone_and_in_a_large_batch(engine):
         assert np.array_equal(pred_1[0, :l1[0]], pred_b[k, :lens[k]])
         a1, off1 = engine.decode(noise=noise_b.reshape(-1, 9)[off_b[k]:off_b[k + 1]].reshape(-1))
         assert np.array_equal(a1, audio_b[off_b[k]:off_b[k + 1]]), float(np.abs(a1 - audio_b[off_b[k]:off_b[k + 1]]).max())
+
+
+@pytest.mark.gpu
+def test_split_and_streaming_lstm_kernels_give_the_same_bits(engine, monkeypatch):
+    """lstm_split_kernel (four workgroups per recurrence, W_hh in registers, per-step exchange of h through global
+    memory) against lstm_kernel (one workgroup streaming W_hh from L2): same chains, same partial-sum tree -- a second
+    engine built with K82_LSTM_SPLIT_MAX_B=0 (streaming kernel everywhere) must reproduce durations and audio exactly,
+    for a batch large enough that the split grid (8 workgroups per sentence) runs in more than one round."""
+    from tts_amd.engine import Engine
+    lengths = [37, 90, 12, 254] + [40 + (11 * i) % 70 for i in range(36)]
+    id_lists, ref_s = H.make_batch(5, lengths)
+    ids, lens = engine.pack(id_lists)
+    pred_a, nfr_a = engine.durations(ids, lens, ref_s)
+    noise = _noise_for(nfr_a)
+    audio_a, off_a = engine.decode(noise=noise)
+    audio_a = audio_a.copy()
+    monkeypatch.setenv("K82_LSTM_SPLIT_MAX_B", "0")
+    ref_engine = Engine(spec.synthetic_state_dicts(0))
+    try:
+        pred_r, nfr_r = ref_engine.durations(ids, lens, ref_s)
+        audio_r, off_r = ref_engine.decode(noise=noise)
+        assert np.array_equal(pred_a, pred_r) and np.array_equal(off_a, off_r)
+        assert np.array_equal(audio_a, audio_r), float(np.abs(audio_a - audio_r).max())
+    finally:
+        ref_engine.close()

@@ -149,7 +149,7 @@ struct k82_handle {
     bool have_phase1 = false;
     int* lstm_err = nullptr;           // device word: set by lstm_split_kernel if a cross-workgroup wait ran out
     int lstm_err_h = 0;
-    int lstm_split_max_b = 0;          // CUs / 16, set in finalize()
+    int lstm_split_max_b = 0;          // set in finalize(): CUs / 2 (K82_LSTM_SPLIT_MAX_B=0 selects the streaming kernel everywhere)
     void check_lstm() {                // at points where the stream has just been synchronised
         HIPCHK(hipMemcpy(&lstm_err_h, lstm_err, sizeof(int), hipMemcpyDeviceToHost));
         REQUIRE(lstm_err_h == 0, K82_EHIP, "LSTM recurrence: a workgroup waited too long for its partners (results invalid)");
@@ -526,7 +526,9 @@ struct k82_handle {
         {
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, device));
-            lstm_split_max_b = prop.multiProcessorCount / 16;      // measured on 256 CUs: faster than streaming up to B = 16
+            // beyond CUs / 8 sentences the split grid runs in rounds of ~2.6 us per step each; the streaming kernel's
+            // 9-14 us per step is better from about five rounds on
+            lstm_split_max_b = prop.multiProcessorCount / 2;
             if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));   // A/B only
         }
         lstm_err = (int*)wmalloc(sizeof(int));

@@ -80,10 +80,10 @@ void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float*
                  LenSpec ls, int B, hipStream_t s);
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
                        int B, float* hx, int* flags, int* err, hipStream_t s);
-// the split recurrence needs every workgroup of its grid resident at once (8 per sentence, one per CU) and its flag
-// polling scales with the number of recurrences in flight: measured per configs[1]-shaped step, split vs streaming
-// kernel: B = 16: 22 vs 27 ms, B = 24: 33 vs 28, B = 32: 45 vs 28, B = 64 (two rounds): 89 vs 39 -- the engine uses it
-// for B <= CUs / 16
+// The split recurrence is used up to CUs / 2 sentences (four rounds of the grid).  Its four workgroups per (direction, sentence) are adjacent in
+// dispatch order; with more than CUs / 8 sentences the grid runs in rounds (in-order dispatch: at most one recurrence
+// straddles the residency boundary and gets its missing parts as soon as any complete one finishes).  Per
+// configs[1]-shaped step, split vs streaming kernel: B = 16: 9.4 vs 26.6 ms, B = 32: 10.1 vs 28.0, B = 64: 19.6 vs 36.2.
 // rows [r0, r0+n) of y get value v[b*vstride + voff + i] for t < L_b (style broadcast)
 void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
                       LenSpec ls, int B, int Tmax, hipStream_t s);

@@ -394,6 +394,9 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, i
 // Co-residency: the four parts of a recurrence are adjacent in dispatch order and the launcher uses this kernel only
 // when every workgroup of the grid fits on the chip at once (one 512-thread, 256-VGPR workgroup per CU); a spin that
 // exceeds its bound sets *err and every wave leaves its loop.
+#ifndef K82_LSTM_SLEEP
+#define K82_LSTM_SLEEP 2
+#endif
 __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
                                                            long ybs, int ypitch, LenSpec ls, float* hx, int* flags, int* err) {
     __shared__ __attribute__((aligned(16))) float hbuf[256];
@@ -452,16 +455,22 @@ __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, lon
             c = fg * c + ig * gg;
             const float hn = og * tanhf(c);
             yo[t] = hn;
+            // Every access to the exchange buffer and the counter is a device-scope atomic, i.e. it bypasses the
+            // non-coherent caches by itself; the only ordering needed is "my 64 stores are acknowledged before my
+            // arrival is counted", which is this wave's own vmcnt(0).  (Release / acquire fences would be correct too,
+            // but on this chip they write back and invalidate the L2 -- per workgroup and step; measured: the step
+            // time then grows linearly with the number of recurrences in flight.)
             __hip_atomic_store(&H[(s & 1) * 256 + j], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            if (tid == 0) __hip_atomic_store(&F[P], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid < 4) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) {                    // one arrival counter per recurrence, one polling lane per workgroup
+                __hip_atomic_fetch_add(&F[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int spins = 0;
-                while (__hip_atomic_load(&F[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < s + 1) {
+                while (__hip_atomic_load(&F[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (s + 1)) {
                     if (++spins > (1 << 20)) { dead = 1; *err = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(K82_LSTM_SLEEP);
                 }
             }
+            asm volatile("" ::: "memory");
         }
         __syncthreads();
         if (dead) break;
