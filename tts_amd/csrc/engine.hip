@@ -149,6 +149,7 @@ struct k82_handle {
     bool have_phase1 = false;
     int* lstm_err = nullptr;           // device word: set by lstm_split_kernel if a cross-workgroup wait ran out
     int lstm_err_h = 0;
+    int cus = 0;
     int lstm_split_max_b = 0;          // set in finalize(): CUs / 2 (K82_LSTM_SPLIT_MAX_B=0 selects the streaming kernel everywhere)
     void check_lstm() {                // at points where the stream has just been synchronised
         HIPCHK(hipMemcpy(&lstm_err_h, lstm_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -528,7 +529,8 @@ struct k82_handle {
             HIPCHK(hipGetDeviceProperties(&prop, device));
             // beyond CUs / 8 sentences the split grid runs in rounds of ~2.6 us per step each; the streaming kernel's
             // 9-14 us per step is better from about five rounds on
-            lstm_split_max_b = prop.multiProcessorCount / 2;
+            cus = prop.multiProcessorCount;
+            lstm_split_max_b = cus / 2;          // 4 sentences per workgroup: one resident round up to CUs / 2 sentences
             if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));   // A/B only
         }
         lstm_err = (int*)wmalloc(sizeof(int));
@@ -650,9 +652,9 @@ struct k82_handle {
         ConvP p = cp(L.ih, x, xbs, xpitch, gx, (long)2048 * gp, gp, ls, ls, B, Lmax);
         run_conv(p, hbase);
         if (B <= lstm_split_max_b) {      // few sentences: the weight-resident four-workgroup recurrence (same bits)
-            float* hx = ar.f((size_t)B * 1024);
+            float* hx = ar.f((size_t)ru(B, 4) * 1024);
             int* flags = (int*)ar.alloc((size_t)B * 8 * sizeof(int));
-            timed(FAM_LSTM, steps, [&] { launch_lstm_split(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, hx, flags, lstm_err, st); });
+            timed(FAM_LSTM, steps, [&] { launch_lstm_split(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, hx, flags, lstm_err, cus, st); });
         } else {
             timed(FAM_LSTM, steps, [&] { launch_lstm(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, st); });
         }

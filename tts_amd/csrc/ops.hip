@@ -397,75 +397,99 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, i
 #ifndef K82_LSTM_SLEEP
 #define K82_LSTM_SLEEP 2
 #endif
+// NS sentences per workgroup share the register-resident weights (the launcher picks NS so that the whole grid is
+// resident in ONE round: 8 * ceil(B / NS) workgroups <= CUs): the per-step exchange latency is paid once for NS
+// recurrences; each sentence keeps its own chains, so the bits do not depend on NS.
+template <int NS>
 __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
-                                                           long ybs, int ypitch, LenSpec ls, float* hx, int* flags, int* err) {
-    __shared__ __attribute__((aligned(16))) float hbuf[256];
-    __shared__ float2 part[4][2][64];
+                                                           long ybs, int ypitch, LenSpec ls, int B, float* hx, int* flags, int* err) {
+    __shared__ __attribute__((aligned(16))) float hbuf[NS][256];
+    __shared__ float2 part[NS][4][2][64];
     __shared__ int dead;
-    const int P = blockIdx.x & 3, dir = (blockIdx.x >> 2) & 1, b = blockIdx.x >> 3;
+    const int P = blockIdx.x & 3, dir = (blockIdx.x >> 2) & 1, grp = blockIdx.x >> 3, b0 = grp * NS;
     const int tid = threadIdx.x, pt = tid >> 7, g2 = (tid >> 6) & 1, jl = tid & 63, j = 64 * P + jl;
-    const int T = ls.len(b);
+    int Tn[NS], Tmax = 0;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) { Tn[n] = b0 + n < B ? ls.len(b0 + n) : 0; Tmax = max(Tmax, Tn[n]); }
     float2 w[64];
     {
         const float4* W = reinterpret_cast<const float4*>(whh) + (long)dir * 256 * 256 + (long)(64 * pt) * 256 + j;
 #pragma unroll
         for (int k = 0; k < 64; ++k) w[k] = reinterpret_cast<const float2*>(W + (long)k * 256)[g2];
     }
-    const float* g0 = gx + (long)b * gbs + (long)(dir * 1024 + j) * gpitch;
+    // gate stage: wave n (tid < 64 NS) finishes sentence n, lane = one of this workgroup's 64 hidden units
+    const int fn = min(tid >> 6, NS - 1), fb = min(b0 + fn, B - 1);
+    const bool fin = tid < 64 * NS;
+    int Tf = 0;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) Tf = (fn == n) ? Tn[n] : Tf;
+    const float* g0 = gx + (long)fb * gbs + (long)(dir * 1024 + j) * gpitch;
     const long gs = (long)256 * gpitch;
-    float* yo = y + (long)b * ybs + (long)(dir * 256 + j) * ypitch;
-    float* H = hx + (long)(b * 2 + dir) * 512;
-    int* F = flags + (b * 2 + dir) * 4;
+    float* yo = y + (long)fb * ybs + (long)(dir * 256 + j) * ypitch;
+    float* H = hx + (long)(grp * 2 + dir) * (2 * NS * 256);
+    int* F = flags + (grp * 2 + dir) * 4;
     float c = 0.f;
-    if (tid < 256) hbuf[tid] = 0.f;
+    if (tid < 256)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) hbuf[n][tid] = 0.f;
     if (tid == 0) dead = 0;
     float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 64 && T > 0) {
-        const int t0 = dir ? T - 1 : 0;
+    if (fin && Tf > 0) {
+        const int t0 = dir ? Tf - 1 : 0;
         gn = make_float4(g0[t0], g0[gs + t0], g0[2 * gs + t0], g0[3 * gs + t0]);
     }
     __syncthreads();
-    for (int s = 0; s < T; ++s) {
-        const int t = dir ? T - 1 - s : s;
+    for (int s = 0; s < Tmax; ++s) {
+        const int t = dir ? Tf - 1 - s : s;
         const float4 gcur = gn;
-        if (tid < 64 && s + 1 < T) {
+        if (fin && s + 1 < Tf) {
             const int tn = dir ? t - 1 : t + 1;
             gn = make_float4(g0[tn], g0[gs + tn], g0[2 * gs + tn], g0[3 * gs + tn]);
         }
-        float a0 = 0.f, a1 = 0.f;
-        const float4* h4 = reinterpret_cast<const float4*>(hbuf) + 16 * pt;
+        // all NS recurrences every step, finished ones included (their sums are never read): no branch sits between
+        // the 2 NS independent chains of 64 dependent FMAs, so they interleave and hide each other's latency
+        float a0[NS], a1[NS];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) { a0[n] = 0.f; a1[n] = 0.f; }
 #pragma unroll
         for (int k4 = 0; k4 < 16; ++k4) {
-            const float4 hv = h4[k4];
-            a0 += w[4 * k4 + 0].x * hv.x; a1 += w[4 * k4 + 0].y * hv.x;
-            a0 += w[4 * k4 + 1].x * hv.y; a1 += w[4 * k4 + 1].y * hv.y;
-            a0 += w[4 * k4 + 2].x * hv.z; a1 += w[4 * k4 + 2].y * hv.z;
-            a0 += w[4 * k4 + 3].x * hv.w; a1 += w[4 * k4 + 3].y * hv.w;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const float4 hv = (reinterpret_cast<const float4*>(hbuf[n]) + 16 * pt)[k4];
+                a0[n] += w[4 * k4 + 0].x * hv.x; a1[n] += w[4 * k4 + 0].y * hv.x;
+                a0[n] += w[4 * k4 + 1].x * hv.y; a1[n] += w[4 * k4 + 1].y * hv.y;
+                a0[n] += w[4 * k4 + 2].x * hv.z; a1[n] += w[4 * k4 + 2].y * hv.z;
+                a0[n] += w[4 * k4 + 3].x * hv.w; a1[n] += w[4 * k4 + 3].y * hv.w;
+            }
         }
-        part[pt][g2][jl] = make_float2(a0, a1);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) part[n][pt][g2][jl] = make_float2(a0[n], a1[n]);
         __syncthreads();
-        if (tid < 64) {
-            const float2 i0 = part[0][0][jl], i1 = part[1][0][jl], i2 = part[2][0][jl], i3 = part[3][0][jl];
-            const float2 o0 = part[0][1][jl], o1 = part[1][1][jl], o2 = part[2][1][jl], o3 = part[3][1][jl];
-            const float ai = gcur.x + ((i0.x + i1.x) + (i2.x + i3.x));
-            const float af = gcur.y + ((i0.y + i1.y) + (i2.y + i3.y));
-            const float ag = gcur.z + ((o0.x + o1.x) + (o2.x + o3.x));
-            const float ao = gcur.w + ((o0.y + o1.y) + (o2.y + o3.y));
-            const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanhf(ag), og = sigmoidf_(ao);
-            c = fg * c + ig * gg;
-            const float hn = og * tanhf(c);
-            yo[t] = hn;
-            // Every access to the exchange buffer and the counter is a device-scope atomic, i.e. it bypasses the
-            // non-coherent caches by itself; the only ordering needed is "my 64 stores are acknowledged before my
-            // arrival is counted", which is this wave's own vmcnt(0).  (Release / acquire fences would be correct too,
-            // but on this chip they write back and invalidate the L2 -- per workgroup and step; measured: the step
-            // time then grows linearly with the number of recurrences in flight.)
-            __hip_atomic_store(&H[(s & 1) * 256 + j], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) {                    // one arrival counter per recurrence, one polling lane per workgroup
-                __hip_atomic_fetch_add(&F[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin) {
+            if (s < Tf) {                                      // wave-uniform
+                const float2 i0 = part[fn][0][0][jl], i1 = part[fn][1][0][jl], i2 = part[fn][2][0][jl], i3 = part[fn][3][0][jl];
+                const float2 o0 = part[fn][0][1][jl], o1 = part[fn][1][1][jl], o2 = part[fn][2][1][jl], o3 = part[fn][3][1][jl];
+                const float ai = gcur.x + ((i0.x + i1.x) + (i2.x + i3.x));
+                const float af = gcur.y + ((i0.y + i1.y) + (i2.y + i3.y));
+                const float ag = gcur.z + ((o0.x + o1.x) + (o2.x + o3.x));
+                const float ao = gcur.w + ((o0.y + o1.y) + (o2.y + o3.y));
+                const float ig = sigmoidf_(ai), fg = sigmoidf_(af), gg = tanhf(ag), og = sigmoidf_(ao);
+                c = fg * c + ig * gg;
+                const float hn = og * tanhf(c);
+                yo[t] = hn;
+                // Every access to the exchange buffer and the counter is a device-scope atomic, i.e. it bypasses the
+                // non-coherent caches by itself; the only ordering needed is "my 64 stores are acknowledged before my
+                // arrival is counted", which is this wave's own vmcnt(0).  (Release / acquire fences would be correct
+                // too, but on this chip they write back and invalidate the L2 -- per workgroup and step; measured: the
+                // step time then grows linearly with the number of recurrences in flight.)
+                __hip_atomic_store(&H[((s & 1) * NS + fn) * 256 + j], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // one arrival counter per (group, direction): every gate wave of its four workgroups arrives once per step
+            if (jl == 0) __hip_atomic_fetch_add(&F[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
                 int spins = 0;
-                while (__hip_atomic_load(&F[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (s + 1)) {
+                while (__hip_atomic_load(&F[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * NS * (s + 1)) {
                     if (++spins > (1 << 20)) { dead = 1; *err = 1; break; }
                     __builtin_amdgcn_s_sleep(K82_LSTM_SLEEP);
                 }
@@ -474,7 +498,14 @@ __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, lon
         }
         __syncthreads();
         if (dead) break;
-        if (tid < 256) hbuf[tid] = __hip_atomic_load(&H[(s & 1) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 256) {                                       // all NS loads in flight together (a finished sentence's slot is stale: unused)
+            float hv[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+                hv[n] = __hip_atomic_load(&H[((s & 1) * NS + n) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) hbuf[n][tid] = hv[n];
+        }
         __syncthreads();
     }
 }
@@ -482,11 +513,17 @@ void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float*
                  int B, hipStream_t s) {
     hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(1024), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
 }
-// hx: float[B][2][2][256] exchange buffer, flags: int[B][2][4] zeroed here, err: one device int (sticky)
+// hx: float[ceil(B / NS) * NS][2][2][256] exchange buffer (1024 floats per sentence, B rounded up to 4), flags:
+// int[B][2][4] zeroed here, err: one device int (sticky); cus: CUs of the device
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
-                       int B, float* hx, int* flags, int* err, hipStream_t s) {
+                       int B, float* hx, int* flags, int* err, int cus, hipStream_t s) {
     (void)hipMemsetAsync(flags, 0, (size_t)B * 8 * sizeof(int), s);
-    hipLaunchKernelGGL(lstm_split_kernel, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, hx, flags, err);
+    if (8 * B <= cus)
+        hipLaunchKernelGGL(lstm_split_kernel<1>, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
+    else if (8 * ((B + 1) / 2) <= cus)
+        hipLaunchKernelGGL(lstm_split_kernel<2>, dim3(8 * ((B + 1) / 2)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
+    else
+        hipLaunchKernelGGL(lstm_split_kernel<4>, dim3(8 * ((B + 3) / 4)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
 }
 
 // ------------------------------------------------------------------------ small helpers
