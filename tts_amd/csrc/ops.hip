@@ -426,8 +426,8 @@ __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, lon
     const float* g0 = gx + (long)fb * gbs + (long)(dir * 1024 + j) * gpitch;
     const long gs = (long)256 * gpitch;
     float* yo = y + (long)fb * ybs + (long)(dir * 256 + j) * ypitch;
-    float* H = hx + (long)(grp * 2 + dir) * (2 * NS * 256);
-    int* F = flags + (grp * 2 + dir) * 4;
+    // exchange buffer: one 8-byte (value, step) word per hidden unit, sentence and step parity
+    unsigned long long* H = reinterpret_cast<unsigned long long*>(hx) + (long)(grp * 2 + dir) * (2 * NS * 256);
     float c = 0.f;
     if (tid < 256)
 #pragma unroll
@@ -477,47 +477,45 @@ __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, lon
                 c = fg * c + ig * gg;
                 const float hn = og * tanhf(c);
                 yo[t] = hn;
-                // Every access to the exchange buffer and the counter is a device-scope atomic, i.e. it bypasses the
-                // non-coherent caches by itself; the only ordering needed is "my 64 stores are acknowledged before my
-                // arrival is counted", which is this wave's own vmcnt(0).  (Release / acquire fences would be correct
-                // too, but on this chip they write back and invalidate the L2 -- per workgroup and step; measured: the
-                // step time then grows linearly with the number of recurrences in flight.)
-                __hip_atomic_store(&H[((s & 1) * NS + fn) * 256 + j], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // The new h travels as ONE 8-byte device-scope atomic store of (value, step): single-copy atomic, it
+                // bypasses the non-coherent caches by itself, and a reader that sees the step tag has the value -- no
+                // flag, no counter, no fence, no wait for the store's acknowledgement (a release fence would also
+                // write back, and an acquire invalidate, the L2 on this chip: per workgroup and step).
+                const unsigned long long word = ((unsigned long long)(unsigned)(s + 1) << 32) | (unsigned long long)__float_as_uint(hn);
+                __hip_atomic_store(&H[((s & 1) * NS + fn) * 256 + j], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // one arrival counter per (group, direction): every gate wave of its four workgroups arrives once per step
-            if (jl == 0) __hip_atomic_fetch_add(&F[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(&F[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * NS * (s + 1)) {
-                    if (++spins > (1 << 20)) { dead = 1; *err = 1; break; }
-                    __builtin_amdgcn_s_sleep(K82_LSTM_SLEEP);
+        }
+        // every thread fetches one unit of each live sentence, spinning (bounded) until its step tag arrives
+        if (tid < 256) {
+            unsigned long long hw[NS];
+            int spins = 0;
+            bool all;
+            do {
+                all = true;
+#pragma unroll
+                for (int n = 0; n < NS; ++n) {
+                    hw[n] = __hip_atomic_load(&H[((s & 1) * NS + n) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    all = all && (s >= Tn[n] || (unsigned)(hw[n] >> 32) == (unsigned)(s + 1));
                 }
-            }
-            asm volatile("" ::: "memory");
+                if (!all && ++spins > (1 << 18)) { dead = 1; *err = 1; break; }
+            } while (!all);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) hbuf[n][tid] = __uint_as_float((unsigned)hw[n]);
         }
         __syncthreads();
         if (dead) break;
-        if (tid < 256) {                                       // all NS loads in flight together (a finished sentence's slot is stale: unused)
-            float hv[NS];
-#pragma unroll
-            for (int n = 0; n < NS; ++n)
-                hv[n] = __hip_atomic_load(&H[((s & 1) * NS + n) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int n = 0; n < NS; ++n) hbuf[n][tid] = hv[n];
-        }
-        __syncthreads();
     }
 }
 void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
                  int B, hipStream_t s) {
     hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(1024), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
 }
-// hx: float[ceil(B / NS) * NS][2][2][256] exchange buffer (1024 floats per sentence, B rounded up to 4), flags:
-// int[B][2][4] zeroed here, err: one device int (sticky); cus: CUs of the device
+// hx: exchange buffer of 8-byte (value, step) words [ceil(B / NS)][2 dirs][2 parities][NS][256], i.e. 2048 floats per
+// sentence with B rounded up to 4, zeroed here; flags: unused; err: one device int (sticky); cus: CUs of the device
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
                        int B, float* hx, int* flags, int* err, int cus, hipStream_t s) {
-    (void)hipMemsetAsync(flags, 0, (size_t)B * 8 * sizeof(int), s);
+    (void)flags;
+    (void)hipMemsetAsync(hx, 0, (size_t)((B + 3) / 4 * 4) * 2048 * sizeof(float), s);      // step tags start at 0
     if (8 * B <= cus)
         hipLaunchKernelGGL(lstm_split_kernel<1>, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
     else if (8 * ((B + 1) / 2) <= cus)
