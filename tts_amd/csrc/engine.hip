@@ -653,8 +653,7 @@ struct k82_handle {
         run_conv(p, hbase);
         if (B <= lstm_split_max_b) {      // few sentences: the weight-resident four-workgroup recurrence (same bits)
             float* hx = ar.f((size_t)ru(B, 4) * 2048);
-            int* flags = (int*)ar.alloc((size_t)B * 8 * sizeof(int));
-            timed(FAM_LSTM, steps, [&] { launch_lstm_split(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, hx, flags, lstm_err, cus, st); });
+            timed(FAM_LSTM, steps, [&] { launch_lstm_split(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, hx, lstm_err, cus, st); });
         } else {
             timed(FAM_LSTM, steps, [&] { launch_lstm(gx, (long)2048 * gp, gp, L.whh, y, ybs, ypitch, ls, B, st); });
         }

@@ -79,7 +79,7 @@ void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long c
 void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch,
                  LenSpec ls, int B, hipStream_t s);
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
-                       int B, float* hx, int* flags, int* err, int cus, hipStream_t s);
+                       int B, float* hx, int* err, int cus, hipStream_t s);
 // The split recurrence is used up to CUs / 2 sentences (four rounds of the grid).  Its four workgroups per (direction, sentence) are adjacent in
 // dispatch order; with more than CUs / 8 sentences the grid runs in rounds (in-order dispatch: at most one recurrence
 // straddles the residency boundary and gets its missing parts as soon as any complete one finishes).  Per

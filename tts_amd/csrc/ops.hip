@@ -384,25 +384,22 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, i
         p ^= 1;
     }
 }
-// Small batches (single sentences): one (direction, sentence) recurrence spread over FOUR workgroups, 64 hidden units
+// Up to CUs / 2 sentences: one (direction, sentence) recurrence spread over FOUR workgroups, 64 hidden units
 // each, with the unit's W_hh rows RESIDENT IN REGISTERS (thread = k-quarter x unit x gate pair: 64 k x 2 gates = 128
 // VGPRs) instead of 1 MB streamed from L2 through one CU every step (7.8 us at 64 B/clk -- the step time of the
 // kernel above when only two workgroups run).  Per step each workgroup publishes its 64 new h values in global memory
-// and waits for the other three (device-scope flags, bounded spin).  Arithmetic is IDENTICAL to lstm_kernel's: the
+// as (value, step) words that the other three poll (bounded spin).  Arithmetic is IDENTICAL to lstm_kernel's: the
 // same four k-quarter chains per gate in the same order, the same partial-sum tree, the same gate code -- a sentence
 // gives the same bits alone (this kernel) and in a large batch (that kernel).
 // Co-residency: the four parts of a recurrence are adjacent in dispatch order and the launcher uses this kernel only
 // when every workgroup of the grid fits on the chip at once (one 512-thread, 256-VGPR workgroup per CU); a spin that
 // exceeds its bound sets *err and every wave leaves its loop.
-#ifndef K82_LSTM_SLEEP
-#define K82_LSTM_SLEEP 2
-#endif
 // NS sentences per workgroup share the register-resident weights (the launcher picks NS so that the whole grid is
 // resident in ONE round: 8 * ceil(B / NS) workgroups <= CUs): the per-step exchange latency is paid once for NS
 // recurrences; each sentence keeps its own chains, so the bits do not depend on NS.
 template <int NS>
 __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
-                                                           long ybs, int ypitch, LenSpec ls, int B, float* hx, int* flags, int* err) {
+                                                           long ybs, int ypitch, LenSpec ls, int B, float* hx, int* err) {
     __shared__ __attribute__((aligned(16))) float hbuf[NS][256];
     __shared__ float2 part[NS][4][2][64];
     __shared__ int dead;
@@ -511,17 +508,16 @@ void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float*
     hipLaunchKernelGGL(lstm_kernel, dim3(2, B), dim3(1024), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls);
 }
 // hx: exchange buffer of 8-byte (value, step) words [ceil(B / NS)][2 dirs][2 parities][NS][256], i.e. 2048 floats per
-// sentence with B rounded up to 4, zeroed here; flags: unused; err: one device int (sticky); cus: CUs of the device
+// sentence with B rounded up to 4, zeroed here; err: one device int (sticky); cus: CUs of the device
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
-                       int B, float* hx, int* flags, int* err, int cus, hipStream_t s) {
-    (void)flags;
+                       int B, float* hx, int* err, int cus, hipStream_t s) {
     (void)hipMemsetAsync(hx, 0, (size_t)((B + 3) / 4 * 4) * 2048 * sizeof(float), s);      // step tags start at 0
     if (8 * B <= cus)
-        hipLaunchKernelGGL(lstm_split_kernel<1>, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
+        hipLaunchKernelGGL(lstm_split_kernel<1>, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err);
     else if (8 * ((B + 1) / 2) <= cus)
-        hipLaunchKernelGGL(lstm_split_kernel<2>, dim3(8 * ((B + 1) / 2)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
+        hipLaunchKernelGGL(lstm_split_kernel<2>, dim3(8 * ((B + 1) / 2)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err);
     else
-        hipLaunchKernelGGL(lstm_split_kernel<4>, dim3(8 * ((B + 3) / 4)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, flags, err);
+        hipLaunchKernelGGL(lstm_split_kernel<4>, dim3(8 * ((B + 3) / 4)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err);
 }
 
 // ------------------------------------------------------------------------ small helpers
