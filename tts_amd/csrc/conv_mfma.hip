@@ -678,6 +678,6 @@ void launch_conv(const ConvP& p, hipStream_t s) {
 double conv_flops(const ConvP& p, const int* host_lens) {
     double L = 0;
     for (int b = 0; b < p.B; ++b) L += host_lens ? (double)p.lout.lmul * host_lens[b] + p.lout.ladd : p.lout.ladd;
-    const double taps = p.up_s ? 2.0 : (double)p.taps;
+    const double taps = (p.up_s || p.tapmask) ? 2.0 : (double)p.taps;      // transposed-conv phase rows: 2 of the 3 taps are non-zero
     return 2.0 * p.cout * (double)p.cin * taps * L;
 }

@@ -46,17 +46,26 @@ struct Arena {
     std::vector<Chunk> chunks;
     size_t cur = 0, off = 0, chunk_default = (size_t)256 << 20;
     size_t pass_bytes = 0, high = 0;
-    void reset() {
+    // Folds a pass that had to grow into one chunk.  The caller guarantees that nothing of the pass is still
+    // running (decode() calls it behind its stream synchronize, so the pass that grew pays for the fold, not the
+    // next one).
+    void fold() {
         high = std::max(high, pass_bytes);
+        if (chunks.size() <= 1) return;
+        for (auto& c : chunks) (void)hipFree(c.p);
+        chunks.clear();
+        Chunk c;
+        c.cap = high + high / 8 + ((size_t)64 << 20);
+        if (hipMalloc((void**)&c.p, c.cap) == hipSuccess) chunks.push_back(c);
+        else (void)hipGetLastError();                       // fall back to growing on demand
+        cur = 0; off = 0;
+    }
+    void reset() {
         if (chunks.size() > 1) {
             (void)hipDeviceSynchronize();                   // nothing of the previous pass may still be running
-            for (auto& c : chunks) (void)hipFree(c.p);
-            chunks.clear();
-            Chunk c;
-            c.cap = high + high / 8 + ((size_t)64 << 20);
-            if (hipMalloc((void**)&c.p, c.cap) == hipSuccess) chunks.push_back(c);
-            else (void)hipGetLastError();                   // fall back to growing on demand
+            fold();
         }
+        high = std::max(high, pass_bytes);
         cur = 0; off = 0; pass_bytes = 0;
     }
     void* alloc(size_t bytes) {
@@ -905,11 +914,13 @@ struct k82_handle {
         tap("gen0_noise_conv", xsrc0, 256, P20, b0, nb);
         resblock1(nres[0], xsrc0, xsrc0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, nullptr, 0, 1.f, aF);
         tap("gen0_xsource", xsrc0, 256, P20, b0, nb);
-        {
-            ConvP pu = cp(ups0, xdec, (long)512 * P2, P2, x0, b0, P20, l2F, l2F, nb, 2 * Fmax);
+        {   // ConvTranspose1d as a conv over 10 x 256 phase rows (wide epilogue), then the phase interleave + noise add
+            float* yp = aF.f((size_t)nb * ups0.cout * P2);
+            ConvP pu = cp(ups0, xdec, (long)512 * P2, P2, yp, (long)ups0.cout * P2, P2, l2F, l2F, nb, 2 * Fmax);
             pu.tr = TR_SCALE; pu.in_scale = 1.f; pu.act = ACT_LEAKY; pu.slope = 0.1f;
-            pu.res = xsrc0; pu.rbs = b0; pu.rpitch = P20;
+            pu.up_s = 0; pu.up_cout_shift = 0;
             run_conv(pu, hb);
+            timed(FAM_OTHER, 0, [&] { launch_phase_interleave(yp, (long)ups0.cout * P2, P2, x0, b0, P20, xsrc0, b0, P20, l2F, 256, 10, 0, nb, 2 * Fmax, st); });
         }
         for (int j = 0; j < 3; ++j) resblock1(rb[j], x0, xr0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, xs0, j == 0, 1.0f / 3.0f, aF);
         tap("gen0_out", xs0, 256, P20, b0, nb);
@@ -923,11 +934,12 @@ struct k82_handle {
         resblock1(nres[1], xsrc1, xsrc1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, nullptr, 0, 1.f, aF);
         tap("gen1_xsource", xsrc1, 128, P120, b1, nb);
         {
-            ConvP pu = cp(ups1, xs0, b0, P20, x1, b1, P120, l20, l20, nb, 20 * Fmax);
+            float* yp = aF.f((size_t)nb * ups1.cout * P20);
+            ConvP pu = cp(ups1, xs0, b0, P20, yp, (long)ups1.cout * P20, P20, l20, l20, nb, 20 * Fmax);
             pu.act = ACT_LEAKY; pu.slope = 0.1f;
-            pu.up_off = 1;
-            pu.res = xsrc1; pu.rbs = b1; pu.rpitch = P120;
+            pu.up_s = 0; pu.up_cout_shift = 0;
             run_conv(pu, hb);
+            timed(FAM_OTHER, 0, [&] { launch_phase_interleave(yp, (long)ups1.cout * P20, P20, x1, b1, P120, xsrc1, b1, P120, l20, 128, 6, 1, nb, 20 * Fmax, st); });
             timed(FAM_OTHER, 0, [&] { launch_reflect_fix(x1, b1, P120, xsrc1, b1, P120, 128, nb, st); });
         }
         for (int j = 0; j < 3; ++j) resblock1(rb[3 + j], x1, xr1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, xs1, j == 0, 1.0f / 3.0f, aF);
@@ -952,6 +964,7 @@ struct k82_handle {
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         if (nb <= lstm_split_max_b) check_lstm();
+        aF.fold();
     }
 };
 

@@ -679,6 +679,38 @@ void launch_reflect_fix(float* y, long ybs, int ypitch, const float* xs, long xb
     hipLaunchKernelGGL(reflect_fix_kernel, dim3(DIVUP(C, 64), B), dim3(64), 0, s, y, ybs, ypitch, xs, xbs, xpitch, C);
 }
 
+// Phase interleave of a transposed convolution computed as a conv over s * cout phase rows:
+//     y[b][co][s t + r + off] = yp[b][r cout + co][t] + res[b][co][s t + r + off]          (t < Lin_b, r < s)
+// The conv writes its phase-major output with the wide (128-byte row) epilogue, and this pass does the stride-s
+// scatter through LDS so that both its loads and its stores are whole contiguous rows -- the conv's own interleaving
+// epilogue stored single dwords s floats apart (MFMA pipe busy 11 % in the bf16x3 mode, 56 % in fp32).  The addition
+// is the same single fp32 add the fused epilogue performed: identical bits.
+__global__ __launch_bounds__(256) void phase_interleave_kernel(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch,
+                                                              const float* res, long rbs, int rpitch, LenSpec lin, int cout,
+                                                              int s, int off) {
+    __shared__ float tile[16][65];
+    const int b = blockIdx.z, co = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int L = lin.len(b);
+    if (t0 >= L) return;
+    const int n = min(64, L - t0);
+    for (int r = tid >> 6; r < s; r += 4) {
+        const int t = tid & 63;
+        tile[r][t] = t < n ? yp[(long)b * pbs + (long)(r * cout + co) * ppitch + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    const long yo = (long)b * ybs + (long)co * ypitch + (long)s * t0 + off;
+    const long ro = (long)b * rbs + (long)co * rpitch + (long)s * t0 + off;
+    for (int o = tid; o < n * s; o += 256) {
+        const int t = o / s, r = o - t * s;
+        y[yo + o] = tile[r][t] + res[ro + o];
+    }
+}
+void launch_phase_interleave(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch, const float* res, long rbs,
+                             int rpitch, LenSpec lin, int cout, int s, int off, int B, int Lmax, hipStream_t st) {
+    hipLaunchKernelGGL(phase_interleave_kernel, dim3(DIVUP(Lmax, 64), cout, B), dim3(256), 0, st, yp, pbs, ppitch, y, ybs, ypitch,
+                       res, rbs, rpitch, lin, cout, s, off);
+}
+
 // clip(x,-1,1)*32767 -> int16, truncating like numpy's astype('<i2')
 // (basic.tts_kokoro_2_play_pause_works.py:25)
 __global__ void pcm16_kernel(const float* src, int16_t* dst, int64_t n) {
