@@ -920,7 +920,7 @@ struct k82_handle {
             pu.tr = TR_SCALE; pu.in_scale = 1.f; pu.act = ACT_LEAKY; pu.slope = 0.1f;
             pu.up_s = 0; pu.up_cout_shift = 0;
             run_conv(pu, hb);
-            timed(FAM_OTHER, 0, [&] { launch_phase_interleave(yp, (long)ups0.cout * P2, P2, x0, b0, P20, xsrc0, b0, P20, l2F, 256, 10, 0, nb, 2 * Fmax, st); });
+            timed(FAM_OTHER, 0, [&] { REQUIRE(launch_phase_interleave(yp, (long)ups0.cout * P2, P2, x0, b0, P20, xsrc0, b0, P20, l2F, 256, 10, 0, nb, 2 * Fmax, st) == 0, K82_EINVAL, "transposed-conv rate without an interleave kernel"); });
         }
         for (int j = 0; j < 3; ++j) resblock1(rb[j], x0, xr0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, xs0, j == 0, 1.0f / 3.0f, aF);
         tap("gen0_out", xs0, 256, P20, b0, nb);
@@ -939,7 +939,7 @@ struct k82_handle {
             pu.act = ACT_LEAKY; pu.slope = 0.1f;
             pu.up_s = 0; pu.up_cout_shift = 0;
             run_conv(pu, hb);
-            timed(FAM_OTHER, 0, [&] { launch_phase_interleave(yp, (long)ups1.cout * P20, P20, x1, b1, P120, xsrc1, b1, P120, l20, 128, 6, 1, nb, 20 * Fmax, st); });
+            timed(FAM_OTHER, 0, [&] { REQUIRE(launch_phase_interleave(yp, (long)ups1.cout * P20, P20, x1, b1, P120, xsrc1, b1, P120, l20, 128, 6, 1, nb, 20 * Fmax, st) == 0, K82_EINVAL, "transposed-conv rate without an interleave kernel"); });
             timed(FAM_OTHER, 0, [&] { launch_reflect_fix(x1, b1, P120, xsrc1, b1, P120, 128, nb, st); });
         }
         for (int j = 0; j < 3; ++j) resblock1(rb[3 + j], x1, xr1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, xs1, j == 0, 1.0f / 3.0f, aF);

@@ -112,7 +112,7 @@ void launch_src_har(const float* f0, long fbs, const float* ph, long pbs, int pp
 // stride-6 polyphase image harp [B][144][p0]: harp[ci*6+r][q] = har[ci][6q+r-3]
 void launch_stft(const float* har_src, long hbs, const int* nfr, int B, int Fmax,
                  float* har, long bs1, int p1, float* harp, long bs0, int p0, hipStream_t s);
-void launch_phase_interleave(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch, const float* res, long rbs,
+int launch_phase_interleave(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch, const float* res, long rbs,
                              int rpitch, LenSpec lin, int cout, int s, int off, int B, int Lmax, hipStream_t st);
 void launch_reflect_fix(float* y, long ybs, int ypitch, const float* xs, long xbs, int xpitch, int C, int B, hipStream_t s);
 // conv_post output [B][>=22][p1] -> audio: spec=exp(x[:11]), phase=sin(x[11:]), iSTFT n_fft 20 hop 5

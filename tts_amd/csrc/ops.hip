@@ -685,30 +685,34 @@ void launch_reflect_fix(float* y, long ybs, int ypitch, const float* xs, long xb
 // scatter through LDS so that both its loads and its stores are whole contiguous rows -- the conv's own interleaving
 // epilogue stored single dwords s floats apart (MFMA pipe busy 11 % in the bf16x3 mode, 56 % in fp32).  The addition
 // is the same single fp32 add the fused epilogue performed: identical bits.
+template <int S>
 __global__ __launch_bounds__(256) void phase_interleave_kernel(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch,
-                                                              const float* res, long rbs, int rpitch, LenSpec lin, int cout,
-                                                              int s, int off) {
-    __shared__ float tile[16][65];
-    const int b = blockIdx.z, co = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+                                                              const float* res, long rbs, int rpitch, LenSpec lin, int cout, int off) {
+    __shared__ float tile[256 * S];                                  // [t][r]: the output order of this block's span
+    const int b = blockIdx.z, co = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
     const int L = lin.len(b);
     if (t0 >= L) return;
-    const int n = min(64, L - t0);
-    for (int r = tid >> 6; r < s; r += 4) {
-        const int t = tid & 63;
-        tile[r][t] = t < n ? yp[(long)b * pbs + (long)(r * cout + co) * ppitch + t0 + t] : 0.f;
+    const int n = min(256, L - t0);
+    if (tid < n) {
+        const float* src = yp + (long)b * pbs + (long)co * ppitch + t0 + tid;
+#pragma unroll
+        for (int r = 0; r < S; ++r) tile[tid * S + r] = src[(long)r * cout * ppitch];
     }
     __syncthreads();
-    const long yo = (long)b * ybs + (long)co * ypitch + (long)s * t0 + off;
-    const long ro = (long)b * rbs + (long)co * rpitch + (long)s * t0 + off;
-    for (int o = tid; o < n * s; o += 256) {
-        const int t = o / s, r = o - t * s;
-        y[yo + o] = tile[r][t] + res[ro + o];
-    }
+    const long yo = (long)b * ybs + (long)co * ypitch + (long)S * t0 + off;
+    const long ro = (long)b * rbs + (long)co * rpitch + (long)S * t0 + off;
+    for (int o = tid; o < n * S; o += 256) y[yo + o] = tile[o] + res[ro + o];
 }
-void launch_phase_interleave(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch, const float* res, long rbs,
+int launch_phase_interleave(const float* yp, long pbs, int ppitch, float* y, long ybs, int ypitch, const float* res, long rbs,
                              int rpitch, LenSpec lin, int cout, int s, int off, int B, int Lmax, hipStream_t st) {
-    hipLaunchKernelGGL(phase_interleave_kernel, dim3(DIVUP(Lmax, 64), cout, B), dim3(256), 0, st, yp, pbs, ppitch, y, ybs, ypitch,
-                       res, rbs, rpitch, lin, cout, s, off);
+    const dim3 g(DIVUP(Lmax, 256), cout, B);
+    if (s == 10)
+        hipLaunchKernelGGL(phase_interleave_kernel<10>, g, dim3(256), 0, st, yp, pbs, ppitch, y, ybs, ypitch, res, rbs, rpitch, lin, cout, off);
+    else if (s == 6)
+        hipLaunchKernelGGL(phase_interleave_kernel<6>, g, dim3(256), 0, st, yp, pbs, ppitch, y, ybs, ypitch, res, rbs, rpitch, lin, cout, off);
+    else
+        return -1;                                                   // only the model's two rates are built
+    return 0;
 }
 
 // clip(x,-1,1)*32767 -> int16, truncating like numpy's astype('<i2')
