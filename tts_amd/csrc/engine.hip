@@ -907,7 +907,7 @@ struct k82_handle {
         const long b0 = (long)256 * P20, b1 = (long)128 * P120;
         float* xsrc0 = aF.f((size_t)nb * b0);
         float* x0 = aF.f((size_t)nb * b0);
-        float* xr0 = aF.f((size_t)nb * b0);
+        float* xr0 = aF.f((size_t)nb * std::max(b0, (long)ups0.cout * P2));   // also holds the phase rows of ups0 before the resblocks use it
         float* t10 = aF.f((size_t)nb * b0);
         float* xs0 = aF.f((size_t)nb * b0);
         run_conv(cp(nconv0, harp, (long)144 * P20, P20, xsrc0, b0, P20, l20p, l20, nb, 20 * Fmax), hb);
@@ -915,7 +915,7 @@ struct k82_handle {
         resblock1(nres[0], xsrc0, xsrc0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, nullptr, 0, 1.f, aF);
         tap("gen0_xsource", xsrc0, 256, P20, b0, nb);
         {   // ConvTranspose1d as a conv over 10 x 256 phase rows (wide epilogue), then the phase interleave + noise add
-            float* yp = aF.f((size_t)nb * ups0.cout * P2);
+            float* yp = xr0;
             ConvP pu = cp(ups0, xdec, (long)512 * P2, P2, yp, (long)ups0.cout * P2, P2, l2F, l2F, nb, 2 * Fmax);
             pu.tr = TR_SCALE; pu.in_scale = 1.f; pu.act = ACT_LEAKY; pu.slope = 0.1f;
             pu.up_s = 0; pu.up_cout_shift = 0;
@@ -927,14 +927,14 @@ struct k82_handle {
 
         float* xsrc1 = aF.f((size_t)nb * b1);
         float* x1 = aF.f((size_t)nb * b1);
-        float* xr1 = aF.f((size_t)nb * b1);
+        float* xr1 = aF.f((size_t)nb * std::max(b1, (long)ups1.cout * P20));  // also holds the phase rows of ups1
         float* t11 = aF.f((size_t)nb * b1);
         float* xs1 = aF.f((size_t)nb * b1);
         run_conv(cp(nconv1, har, (long)22 * P120, P120, xsrc1, b1, P120, l120, l120, nb, 120 * Fmax + 1), hb);
         resblock1(nres[1], xsrc1, xsrc1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, nullptr, 0, 1.f, aF);
         tap("gen1_xsource", xsrc1, 128, P120, b1, nb);
         {
-            float* yp = aF.f((size_t)nb * ups1.cout * P20);
+            float* yp = xr1;
             ConvP pu = cp(ups1, xs0, b0, P20, yp, (long)ups1.cout * P20, P20, l20, l20, nb, 20 * Fmax);
             pu.act = ACT_LEAKY; pu.slope = 0.1f;
             pu.up_s = 0; pu.up_cout_shift = 0;
