@@ -74,6 +74,16 @@ __device__ __forceinline__ float snake(float v, float al, float ial) {
 //   EPI_ACC    as EPI_RES, then accbuf = (acc_init ? 0 : accbuf) + y * acc_scale; y optional
 //   EPI_SCALAR transposed-conv phase interleave (up_s) / x2 nearest residual (res_shift): dword path
 enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3 };
+// sum over the 8 lanes of a row span (lane & ~7 ... | 7) on the VALU's DPP path (no LDS round trips): the two quad
+// permutes (xor 1, xor 2), then row_half_mirror (lane i <-> 7 - i, the other quad of the eight)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum8(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    return dpp_add<0x141>(v);  // row_half_mirror
+}
 
 // PREC = 1 (bf16): same staging, same epilogues, but the MFMAs are v_mfma_f32_32x32x16_bf16 (fp32 accumulate): the
 // A operand is the pre-packed bf16 weight image (one 16-byte load per lane, row and k-half), the B operand is the
@@ -463,6 +473,19 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
                         u = (u + rs[e]) * p.out_scale;
                         v[e] = u;
                         av[e] = av[e] + u * p.acc_scale;
+                    }
+                    if (p.stat) {                               // wave-uniform: instance-norm partials of this row span
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float u = (t + e < T.Lout) ? v[e] : 0.f;
+                            s1 += u;
+                            s2 = fmaf(u, u, s2);
+                        }
+                        s1 = sum8(s1);
+                        s2 = sum8(s2);
+                        if (c4 == 0 && m < p.cout && t < T.Lout)
+                            p.stat[(long)T.b * p.sbs + (long)m * p.snt + (t >> 5)] = make_float2(s1, s2);
                     }
                     if (m < p.cout && t < T.Lout) {             // stores only under the lane-dependent condition
                         if (EPI != EPI_ACC || p.y)

@@ -159,6 +159,7 @@ struct k82_handle {
     int* lstm_err = nullptr;           // device word: set by lstm_split_kernel if a cross-workgroup wait ran out
     int lstm_err_h = 0;
     int cus = 0;
+    bool fused_stats = true;           // K82_FUSED_STATS=0: every instance-norm statistic from the sweep kernel (A/B only)
     int lstm_split_max_b = 0;          // set in finalize(): CUs / 2 (K82_LSTM_SPLIT_MAX_B=0 selects the streaming kernel everywhere)
     void check_lstm() {                // at points where the stream has just been synchronised
         HIPCHK(hipMemcpy(&lstm_err_h, lstm_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -540,6 +541,7 @@ struct k82_handle {
             // 9-14 us per step is better from about five rounds on
             cus = prop.multiProcessorCount;
             lstm_split_max_b = cus / 2;          // 4 sentences per workgroup: one resident round up to CUs / 2 sentences
+            if (const char* e = std::getenv("K82_FUSED_STATS")) fused_stats = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));   // A/B only
         }
         lstm_err = (int*)wmalloc(sizeof(int));
@@ -579,6 +581,7 @@ struct k82_handle {
         REQUIRE(p.act != ACT_SNAKE || (p.alpha && p.inv_alpha), K82_EINVAL, "snake needs alpha");
         REQUIRE(p.act != ACT_LEAKY || (p.slope >= 0.f && p.slope <= 1.f), K82_EINVAL, "LeakyReLU slope must be in [0, 1]");
         REQUIRE(p.tr != TR_NORM || p.norm, K82_EINVAL, "norm transform needs statistics");
+        REQUIRE(!p.stat || (p.y && !p.up_s && !p.res_shift && p.snt * 32 >= p.Lmax_out), K82_EINVAL, "statistics partials need a stored, plain-layout output");
     }
     void run_conv(const ConvP& p, const int* host_base) {
         check_conv(p);
@@ -635,21 +638,36 @@ struct k82_handle {
     void resblock1(const ResBlock1W& L, const float* x, float* xr, float* t1, long bs, int pitch, LenSpec ls, int Lmax,
                    const int* hbase, double sumL, float* accbuf, int acc_init, float acc_scale, Arena& ar) {
         const int dil[3] = {1, 3, 5};
+        // the statistics of every tensor a conv of this block writes come out of that conv's epilogue (one partial per
+        // row and 32 columns); only the block input is swept by the statistics kernel
+        const int snt = (Lmax + 31) / 32;
+        float2* part = (float2*)ar.alloc((size_t)B * L.C * snt * sizeof(float2));
+        const bool fs = fused_stats;
+        auto fused = [&](int goff) {
+            if (!fs) return (float4*)nullptr;
+            float4* nm = (float4*)ar.alloc((size_t)B * ru(L.C, 16) * sizeof(float4));
+            timed(FAM_STATS, sumL * L.C / 4.0, [&] { launch_adain_finalize(part, (long)L.C * snt, snt, ls, L.C, B, gbd, Gd, goff, nm, ru(L.C, 16), st); });
+            return nm;
+        };
+        float4* n1_next = nullptr;
         for (int i = 0; i < 3; ++i) {
             const float* cur = i == 0 ? x : xr;
-            float4* n1 = stats(cur, bs, pitch, ls, L.C, gbd, Gd, L.n1[i].goff, ar, Lmax, sumL * L.C);
+            float4* n1 = (i == 0 || !fs) ? stats(cur, bs, pitch, ls, L.C, gbd, Gd, L.n1[i].goff, ar, Lmax, sumL * L.C) : n1_next;
             ConvP p1 = cp(L.c1[i], cur, bs, pitch, t1, bs, pitch, ls, ls, B, Lmax, dil[i]);
+            if (fs) { p1.stat = part; p1.sbs = (long)L.C * snt; p1.snt = snt; }
             p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.C, 16);
             p1.act = ACT_SNAKE; p1.alpha = L.a1[i]; p1.inv_alpha = L.ia1[i];
             run_conv(p1, hbase);
-            float4* n2 = stats(t1, bs, pitch, ls, L.C, gbd, Gd, L.n2[i].goff, ar, Lmax, sumL * L.C);
+            float4* n2 = fs ? fused(L.n2[i].goff) : stats(t1, bs, pitch, ls, L.C, gbd, Gd, L.n2[i].goff, ar, Lmax, sumL * L.C);
             const bool last = i == 2 && accbuf;
             ConvP p2 = cp(L.c2[i], t1, bs, pitch, last ? nullptr : xr, bs, pitch, ls, ls, B, Lmax, 1);
             p2.tr = TR_NORM; p2.norm = n2; p2.nstride = ru(L.C, 16);
             p2.act = ACT_SNAKE; p2.alpha = L.a2[i]; p2.inv_alpha = L.ia2[i];
             p2.res = cur; p2.rbs = bs; p2.rpitch = pitch;
             if (last) { p2.accbuf = accbuf; p2.abs_ = bs; p2.apitch = pitch; p2.acc_init = acc_init; p2.acc_scale = acc_scale; }
+            if (i < 2 && fs) { p2.stat = part; p2.sbs = (long)L.C * snt; p2.snt = snt; }
             run_conv(p2, hbase);
+            if (i < 2) n1_next = fused(L.n1[i + 1].goff);
         }
     }
 

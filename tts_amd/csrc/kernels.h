@@ -50,12 +50,19 @@ struct ConvP {
     const unsigned* tapmask;                   // per 64-row M tile: bitmask of non-zero taps (nullptr: all)
     int B, Lmax_out;                           // grid extents
     int dbg;                                   // unused (kept for ABI stability of the test hook)
+    // instance-norm partials of the stored output (wide epilogues only): stat[b*sbs + m*snt + t/32] = (sum y, sum y^2)
+    // over the valid columns of the 32-column span; every entry is written by exactly one wave (no atomics), and the
+    // 32-column granularity does not depend on the tile shape a launch picks.  nullptr: not collected.
+    float2* stat; long sbs; int snt;
 };
 void launch_conv(const ConvP& p, hipStream_t s);
 double conv_flops(const ConvP& p, const int* host_lens);   // algorithmic FLOPs of one launch
 
 // ---- ops.hip ---------------------------------------------------------------------------
 // AdaIN statistics: norm[b*nstride+c] = {mean, rstd, 1+gamma, beta} over t < L_b.
+// The same from the partials a conv epilogue left (ConvP::stat): fp64 sum over ceil(L_b/32) entries per row.
+void launch_adain_finalize(const float2* part, long sbs, int snt, LenSpec ls, int C, int B, const float* gb, int gbstride,
+                           int goff, float4* norm, int nstride, hipStream_t s);
 void launch_adain_stats(const float* x, long xbs, int xpitch, LenSpec ls, int C, int B,
                         const float* gb, int gbstride, int goff,   // gamma at gb[b*gbstride+goff+c], beta at +C
                         float4* norm, int nstride, int Lmax, hipStream_t s);

@@ -19,6 +19,27 @@ __device__ __forceinline__ float wave_sumf(float v) {
 }
 
 // ---------------------------------------------------------------- AdaIN statistics (row a13)
+__device__ __forceinline__ void adain_finish(double s, double q, int L, int b, int c, int C, const float* gb, int gbstride,
+                                             int goff, float4* norm, int nstride) {
+    __shared__ double sh[8];
+    const int tid = threadIdx.x;
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) { sh[w] = s; sh[4 + w] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        s = sh[0] + sh[1] + sh[2] + sh[3];
+        q = sh[4] + sh[5] + sh[6] + sh[7];
+        const double mean = s / L;
+        double var = q / L - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float g = 1.0f + gb[(long)b * gbstride + goff + c];
+        const float be = gb[(long)b * gbstride + goff + C + c];
+        norm[(long)b * nstride + c] = make_float4((float)mean, rstd, g, be);
+    }
+}
 // One workgroup per (c, b) row: one coalesced float4 sweep, sums in fp64 (one-pass mean and
 // E[x^2] are exact enough in double: 53-bit accumulators over <= 2.5e5 fp32 samples).
 __global__ __launch_bounds__(256) void adain_stats_kernel(const float* x, long xbs, int xpitch, LenSpec ls, int C,
@@ -40,23 +61,27 @@ __global__ __launch_bounds__(256) void adain_stats_kernel(const float* x, long x
         s += v;
         q += (double)v * v;
     }
-    __shared__ double sh[8];
-    s = wave_sum(s);
-    q = wave_sum(q);
-    const int w = tid >> 6;
-    if ((tid & 63) == 0) { sh[w] = s; sh[4 + w] = q; }
-    __syncthreads();
-    if (tid == 0) {
-        s = sh[0] + sh[1] + sh[2] + sh[3];
-        q = sh[4] + sh[5] + sh[6] + sh[7];
-        const double mean = s / L;
-        double var = q / L - mean * mean;
-        if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-        const float g = 1.0f + gb[(long)b * gbstride + goff + c];
-        const float be = gb[(long)b * gbstride + goff + C + c];
-        norm[(long)b * nstride + c] = make_float4((float)mean, rstd, g, be);
+    adain_finish(s, q, L, b, c, C, gb, gbstride, goff, norm, nstride);
+}
+// (sum, sum of squares) per 32 columns from the producing conv's epilogue -> the same float4 per row
+__global__ __launch_bounds__(256) void adain_finalize_kernel(const float2* part, long sbs, int snt, LenSpec ls, int C,
+                                                            const float* gb, int gbstride, int goff, float4* norm,
+                                                            int nstride) {
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int L = ls.len(b), nt = (L + 31) >> 5;
+    const float2* pr = part + (long)b * sbs + (long)c * snt;
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < nt; i += 256) {
+        const float2 v = pr[i];
+        s += (double)v.x;
+        q += (double)v.y;
     }
+    adain_finish(s, q, L, b, c, C, gb, gbstride, goff, norm, nstride);
+}
+void launch_adain_finalize(const float2* part, long sbs, int snt, LenSpec ls, int C, int B, const float* gb, int gbstride,
+                           int goff, float4* norm, int nstride, hipStream_t s) {
+    hipLaunchKernelGGL(adain_finalize_kernel, dim3(C, B), dim3(256), 0, s, part, sbs, snt, ls, C, gb, gbstride, goff, norm,
+                       nstride);
 }
 void launch_adain_stats(const float* x, long xbs, int xpitch, LenSpec ls, int C, int B, const float* gb,
                         int gbstride, int goff, float4* norm, int nstride, int Lmax, hipStream_t s) {
