@@ -636,7 +636,8 @@ struct k82_handle {
     // istftnet.AdaINResBlock1.  x: block input (never written unless xr == x); xr: running tensor;
     // accbuf != nullptr: the last conv accumulates its result * acc_scale into accbuf instead of storing.
     void resblock1(const ResBlock1W& L, const float* x, float* xr, float* t1, long bs, int pitch, LenSpec ls, int Lmax,
-                   const int* hbase, double sumL, float* accbuf, int acc_init, float acc_scale, Arena& ar) {
+                   const int* hbase, double sumL, float* accbuf, int acc_init, float acc_scale, Arena& ar,
+                   float4** share = nullptr) {
         const int dil[3] = {1, 3, 5};
         // the statistics of every tensor a conv of this block writes come out of that conv's epilogue (one partial per
         // row and 32 columns); only the block input is swept by the statistics kernel
@@ -652,7 +653,15 @@ struct k82_handle {
         float4* n1_next = nullptr;
         for (int i = 0; i < 3; ++i) {
             const float* cur = i == 0 ? x : xr;
-            float4* n1 = (i == 0 || !fs) ? stats(cur, bs, pitch, ls, L.C, gbd, Gd, L.n1[i].goff, ar, Lmax, sumL * L.C) : n1_next;
+            float4* n1 = n1_next;
+            if (i == 0 && share && *share) {            // a sibling block already swept this input
+                n1 = (float4*)ar.alloc((size_t)B * ru(L.C, 16) * sizeof(float4));
+                const float4* src = *share;
+                timed(FAM_STATS, 0, [&] { launch_adain_regamma(src, n1, ru(L.C, 16), L.C, B, gbd, Gd, L.n1[0].goff, st); });
+            } else if (i == 0 || !fs) {
+                n1 = stats(cur, bs, pitch, ls, L.C, gbd, Gd, L.n1[i].goff, ar, Lmax, sumL * L.C);
+                if (i == 0 && share) *share = n1;
+            }
             ConvP p1 = cp(L.c1[i], cur, bs, pitch, t1, bs, pitch, ls, ls, B, Lmax, dil[i]);
             if (fs) { p1.stat = part; p1.sbs = (long)L.C * snt; p1.snt = snt; }
             p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.C, 16);
@@ -940,7 +949,8 @@ struct k82_handle {
             run_conv(pu, hb);
             timed(FAM_OTHER, 0, [&] { REQUIRE(launch_phase_interleave(yp, (long)ups0.cout * P2, P2, x0, b0, P20, xsrc0, b0, P20, l2F, 256, 10, 0, nb, 2 * Fmax, st) == 0, K82_EINVAL, "transposed-conv rate without an interleave kernel"); });
         }
-        for (int j = 0; j < 3; ++j) resblock1(rb[j], x0, xr0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, xs0, j == 0, 1.0f / 3.0f, aF);
+        float4* sh0 = nullptr;
+        for (int j = 0; j < 3; ++j) resblock1(rb[j], x0, xr0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, xs0, j == 0, 1.0f / 3.0f, aF, &sh0);
         tap("gen0_out", xs0, 256, P20, b0, nb);
 
         float* xsrc1 = aF.f((size_t)nb * b1);
@@ -960,7 +970,8 @@ struct k82_handle {
             timed(FAM_OTHER, 0, [&] { REQUIRE(launch_phase_interleave(yp, (long)ups1.cout * P20, P20, x1, b1, P120, xsrc1, b1, P120, l20, 128, 6, 1, nb, 20 * Fmax, st) == 0, K82_EINVAL, "transposed-conv rate without an interleave kernel"); });
             timed(FAM_OTHER, 0, [&] { launch_reflect_fix(x1, b1, P120, xsrc1, b1, P120, 128, nb, st); });
         }
-        for (int j = 0; j < 3; ++j) resblock1(rb[3 + j], x1, xr1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, xs1, j == 0, 1.0f / 3.0f, aF);
+        float4* sh1 = nullptr;
+        for (int j = 0; j < 3; ++j) resblock1(rb[3 + j], x1, xr1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, xs1, j == 0, 1.0f / 3.0f, aF, &sh1);
         tap("gen1_out", xs1, 128, P120, b1, nb);
 
         float* cpo = aF.f((size_t)nb * 22 * P120);

@@ -63,6 +63,9 @@ double conv_flops(const ConvP& p, const int* host_lens);   // algorithmic FLOPs 
 // The same from the partials a conv epilogue left (ConvP::stat): fp64 sum over ceil(L_b/32) entries per row.
 void launch_adain_finalize(const float2* part, long sbs, int snt, LenSpec ls, int C, int B, const float* gb, int gbstride,
                            int goff, float4* norm, int nstride, hipStream_t s);
+// dst = src with (1+gamma, beta) of another AdaIN layer over the same tensor
+void launch_adain_regamma(const float4* src, float4* dst, int nstride, int C, int B, const float* gb, int gbstride, int goff,
+                          hipStream_t s);
 void launch_adain_stats(const float* x, long xbs, int xpitch, LenSpec ls, int C, int B,
                         const float* gb, int gbstride, int goff,   // gamma at gb[b*gbstride+goff+c], beta at +C
                         float4* norm, int nstride, int Lmax, hipStream_t s);

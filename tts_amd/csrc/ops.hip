@@ -78,6 +78,21 @@ __global__ __launch_bounds__(256) void adain_finalize_kernel(const float2* part,
     }
     adain_finish(s, q, L, b, c, C, gb, gbstride, goff, norm, nstride);
 }
+// The three parallel resblocks of a generator stage normalise the same tensor with their own (gamma, beta): one
+// sweep, then the other two take its (mean, rstd) -- the bits a second sweep would give.
+__global__ __launch_bounds__(256) void adain_regamma_kernel(const float4* src, float4* dst, int nstride, int C, const float* gb,
+                                                           int gbstride, int goff) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float4 v = src[(long)b * nstride + c];
+    v.z = 1.0f + gb[(long)b * gbstride + goff + c];
+    v.w = gb[(long)b * gbstride + goff + C + c];
+    dst[(long)b * nstride + c] = v;
+}
+void launch_adain_regamma(const float4* src, float4* dst, int nstride, int C, int B, const float* gb, int gbstride, int goff,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(adain_regamma_kernel, dim3(DIVUP(C, 256), B), dim3(256), 0, s, src, dst, nstride, C, gb, gbstride, goff);
+}
 void launch_adain_finalize(const float2* part, long sbs, int snt, LenSpec ls, int C, int B, const float* gb, int gbstride,
                            int goff, float4* norm, int nstride, hipStream_t s) {
     hipLaunchKernelGGL(adain_finalize_kernel, dim3(C, B), dim3(256), 0, s, part, sbs, snt, ls, C, gb, gbstride, goff, norm,
