@@ -616,8 +616,18 @@ struct k82_handle {
         float* t1 = ar.f((size_t)nb * L.cout * tp);
         ConvP p1 = cp(L.c1, c1in, c1bs, c1pitch, t1, (long)L.cout * tp, tp, lo, lo, nb, Lo);
         if (!L.up) { p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.cin, 16); p1.act = ACT_LEAKY; p1.slope = 0.2f; }
-        run_conv(p1, hbase);
-        float4* n2 = stats(t1, (long)L.cout * tp, tp, lo, L.cout, gb, gstride, L.n2.goff, ar, Lo, sumL * (L.up ? 2 : 1) * L.cout);
+        float4* n2;
+        if (fused_stats) {                          // conv1's epilogue leaves the partials, no second pass over t1
+            const int snt = (Lo + 31) / 32;
+            float2* part = (float2*)ar.alloc((size_t)nb * L.cout * snt * sizeof(float2));
+            p1.stat = part; p1.sbs = (long)L.cout * snt; p1.snt = snt;
+            run_conv(p1, hbase);
+            n2 = (float4*)ar.alloc((size_t)nb * ru(L.cout, 16) * sizeof(float4));
+            timed(FAM_STATS, sumL * (L.up ? 2 : 1) * L.cout / 4.0, [&] { launch_adain_finalize(part, (long)L.cout * snt, snt, lo, L.cout, nb, gb, gstride, L.n2.goff, n2, ru(L.cout, 16), st); });
+        } else {
+            run_conv(p1, hbase);
+            n2 = stats(t1, (long)L.cout * tp, tp, lo, L.cout, gb, gstride, L.n2.goff, ar, Lo, sumL * (L.up ? 2 : 1) * L.cout);
+        }
         const float* res = x; long rbs = xbs; int rpitch = xpitch;
         if (L.has_sc) {
             const int sp_ = ru(Lmax, 4);
@@ -937,9 +947,21 @@ struct k82_handle {
         float* xr0 = aF.f((size_t)nb * std::max(b0, (long)ups0.cout * P2));   // also holds the phase rows of ups0 before the resblocks use it
         float* t10 = aF.f((size_t)nb * b0);
         float* xs0 = aF.f((size_t)nb * b0);
-        run_conv(cp(nconv0, harp, (long)144 * P20, P20, xsrc0, b0, P20, l20p, l20, nb, 20 * Fmax), hb);
+        // a noise conv also leaves the statistics of its output for the first AdaIN of the noise resblock
+        auto noise_conv = [&](ConvP pn, int C, LenSpec ls, int Lmax, int goff, double elems) -> float4* {
+            if (!fused_stats) { run_conv(pn, hb); return nullptr; }
+            const int snt = (Lmax + 31) / 32;
+            float2* part = (float2*)aF.alloc((size_t)nb * C * snt * sizeof(float2));
+            pn.stat = part; pn.sbs = (long)C * snt; pn.snt = snt;
+            run_conv(pn, hb);
+            float4* nm = (float4*)aF.alloc((size_t)nb * ru(C, 16) * sizeof(float4));
+            timed(FAM_STATS, elems / 4.0, [&] { launch_adain_finalize(part, (long)C * snt, snt, ls, C, nb, gbd, Gd, goff, nm, ru(C, 16), st); });
+            return nm;
+        };
+        float4* nsh0 = noise_conv(cp(nconv0, harp, (long)144 * P20, P20, xsrc0, b0, P20, l20p, l20, nb, 20 * Fmax), 256, l20, 20 * Fmax,
+                                  nres[0].n1[0].goff, 20 * sumF * 256);
         tap("gen0_noise_conv", xsrc0, 256, P20, b0, nb);
-        resblock1(nres[0], xsrc0, xsrc0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, nullptr, 0, 1.f, aF);
+        resblock1(nres[0], xsrc0, xsrc0, t10, b0, P20, l20, 20 * Fmax, hb, 20 * sumF, nullptr, 0, 1.f, aF, &nsh0);
         tap("gen0_xsource", xsrc0, 256, P20, b0, nb);
         {   // ConvTranspose1d as a conv over 10 x 256 phase rows (wide epilogue), then the phase interleave + noise add
             float* yp = xr0;
@@ -958,8 +980,9 @@ struct k82_handle {
         float* xr1 = aF.f((size_t)nb * std::max(b1, (long)ups1.cout * P20));  // also holds the phase rows of ups1
         float* t11 = aF.f((size_t)nb * b1);
         float* xs1 = aF.f((size_t)nb * b1);
-        run_conv(cp(nconv1, har, (long)22 * P120, P120, xsrc1, b1, P120, l120, l120, nb, 120 * Fmax + 1), hb);
-        resblock1(nres[1], xsrc1, xsrc1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, nullptr, 0, 1.f, aF);
+        float4* nsh1 = noise_conv(cp(nconv1, har, (long)22 * P120, P120, xsrc1, b1, P120, l120, l120, nb, 120 * Fmax + 1), 128, l120,
+                                  120 * Fmax + 1, nres[1].n1[0].goff, (120 * sumF + nb) * 128);
+        resblock1(nres[1], xsrc1, xsrc1, t11, b1, P120, l120, 120 * Fmax + 1, hb, 120 * sumF + nb, nullptr, 0, 1.f, aF, &nsh1);
         tap("gen1_xsource", xsrc1, 128, P120, b1, nb);
         {
             float* yp = xr1;
