@@ -526,3 +526,31 @@ def test_split_and_streaming_lstm_kernels_give_the_same_bits(engine, monkeypatch
         assert np.array_equal(audio_a, audio_r), float(np.abs(audio_a - audio_r).max())
     finally:
         ref_engine.close()
+
+
+@pytest.mark.gpu
+def test_epilogue_statistics_match_the_sweep_kernel(engine, monkeypatch):
+    """Instance-norm statistics from the conv epilogues (fp32 partials per row and 32 columns, summed in fp64;
+    conv_mfma.hip ConvP::stat + adain_finalize_kernel) against the all-fp64 sweep of the stored tensor
+    (adain_stats_kernel): a second engine built with K82_FUSED_STATS=0 sweeps everywhere.  Durations do not involve
+    AdaIN and must be identical; the waveform may differ by the rounding of rstd only -- two orders of magnitude inside
+    the 1e-3 waveform bar (istftnet.AdaIN1d -> InstanceNorm1d is what both compute).  Ragged lengths put the last
+    partial of every row on a span that is cut by the sentence length."""
+    from tts_amd.engine import Engine
+    lengths = [37, 90, 12, 254, 65, 33]
+    id_lists, ref_s = H.make_batch(7, lengths)
+    ids, lens = engine.pack(id_lists)
+    pred_a, nfr_a = engine.durations(ids, lens, ref_s)
+    noise = _noise_for(nfr_a)
+    audio_a, off_a = engine.decode(noise=noise)
+    audio_a = audio_a.copy()
+    monkeypatch.setenv("K82_FUSED_STATS", "0")
+    ref_engine = Engine(spec.synthetic_state_dicts(0))
+    try:
+        pred_r, nfr_r = ref_engine.durations(ids, lens, ref_s)
+        audio_r, off_r = ref_engine.decode(noise=noise)
+        assert np.array_equal(pred_a, pred_r) and np.array_equal(off_a, off_r)
+        err = float(np.abs(audio_a - audio_r).max())
+        assert err <= 1e-4, err
+    finally:
+        ref_engine.close()

@@ -599,7 +599,8 @@ struct k82_handle {
 
     // istftnet.AdainResBlk1d.  x [B][cin][xpitch] at length lx; out gets [cout] rows at length (up ? 2 : 1)*lx.
     void resblk1d(const ResBlk1dW& L, const float* x, long xbs, int xpitch, LenSpec lx, int Lmax, const int* hbase,
-                  double sumL, float* out, long obs, int opitch, const float* gb, int gstride, Arena& ar) {
+                  double sumL, float* out, long obs, int opitch, const float* gb, int gstride, Arena& ar,
+                  bool fuse = true) {
         const int nb = B;
         float4* n1 = stats(x, xbs, xpitch, lx, L.cin, gb, gstride, L.n1.goff, ar, Lmax, sumL * L.cin);
         LenSpec lo = lx;
@@ -617,7 +618,9 @@ struct k82_handle {
         ConvP p1 = cp(L.c1, c1in, c1bs, c1pitch, t1, (long)L.cout * tp, tp, lo, lo, nb, Lo);
         if (!L.up) { p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.cin, 16); p1.act = ACT_LEAKY; p1.slope = 0.2f; }
         float4* n2;
-        if (fused_stats) {                          // conv1's epilogue leaves the partials, no second pass over t1
+        // (not in the F0 / N stacks: F0 sets the phase of the harmonic source, where a rounding of rstd -- harmless for any
+        // stage tolerance -- moves the waveform; they keep the all-fp64 sweep)
+        if (fused_stats && fuse) {                  // conv1's epilogue leaves the partials, no second pass over t1
             const int snt = (Lo + 31) / 32;
             float2* part = (float2*)ar.alloc((size_t)nb * L.cout * snt * sizeof(float2));
             p1.stat = part; p1.sbs = (long)L.cout * snt; p1.snt = snt;
@@ -870,11 +873,11 @@ struct k82_handle {
         for (int which = 0; which < 2; ++which) {
             const ResBlk1dW* blk = which ? nblk : f0blk;
             float* a = aF.f((size_t)nb * H * PF);
-            resblk1d(blk[0], sh, (long)H * PF, PF, lF, Fmax, hb, sumF, a, (long)H * PF, PF, gbp, Gp, aF);
+            resblk1d(blk[0], sh, (long)H * PF, PF, lF, Fmax, hb, sumF, a, (long)H * PF, PF, gbp, Gp, aF, false);
             float* bq = aF.f((size_t)nb * (H / 2) * P2);
-            resblk1d(blk[1], a, (long)H * PF, PF, lF, Fmax, hb, sumF, bq, (long)(H / 2) * P2, P2, gbp, Gp, aF);
+            resblk1d(blk[1], a, (long)H * PF, PF, lF, Fmax, hb, sumF, bq, (long)(H / 2) * P2, P2, gbp, Gp, aF, false);
             float* c = aF.f((size_t)nb * (H / 2) * P2);
-            resblk1d(blk[2], bq, (long)(H / 2) * P2, P2, l2F, 2 * Fmax, hb, 2 * sumF, c, (long)(H / 2) * P2, P2, gbp, Gp, aF);
+            resblk1d(blk[2], bq, (long)(H / 2) * P2, P2, l2F, 2 * Fmax, hb, 2 * sumF, c, (long)(H / 2) * P2, P2, gbp, Gp, aF, false);
             run_conv(cp(which ? nproj : f0proj, c, (long)(H / 2) * P2, P2, which ? nn : f0, P2, P2, l2F, l2F, nb, 2 * Fmax), hb);
         }
         tap("F0", f0, 1, P2, P2, nb);
