@@ -655,8 +655,8 @@ struct k82_handle {
         // the statistics of every tensor a conv of this block writes come out of that conv's epilogue (one partial per
         // row and 32 columns); only the block input is swept by the statistics kernel
         const int snt = (Lmax + 31) / 32;
-        float2* part = (float2*)ar.alloc((size_t)B * L.C * snt * sizeof(float2));
         const bool fs = fused_stats;
+        float2* part = fs ? (float2*)ar.alloc((size_t)B * L.C * snt * sizeof(float2)) : nullptr;
         auto fused = [&](int goff) {
             if (!fs) return (float4*)nullptr;
             float4* nm = (float4*)ar.alloc((size_t)B * ru(L.C, 16) * sizeof(float4));
