@@ -8,11 +8,25 @@
  * aborts: every entry point returns 0 or a negative K82_E* code and k82_last_error() explains.
  *
  * Pointer arguments documented "host or device" are classified with hipPointerGetAttributes.
- * A handle serialises its own calls with a mutex, so concurrent calls from several Python
- * threads on one handle are safe (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715 does
- * exactly that with two threads on one Kokoro object).  HIP is initialised lazily by
- * k82_create in the calling process (construction inside a forked/spawned child is fine:
- * basic.tts_kokoro_2_play_pause_works.py:34-41).
+ *
+ * Threads.  A handle serialises its own calls with a mutex, so EACH call is safe from any thread.
+ * k82_synthesize is one call and therefore atomic: it is what concurrent callers use (the reference
+ * runs two pool threads on one Kokoro object, epubviewer_06_latest_1_nov_2025_theme.py:407,692,715,
+ * and a Timer thread, speech7.py:178).  The two-phase form is NOT atomic as a pair: k82_durations
+ * leaves the token-rate state of its batch inside the handle and k82_decode consumes whatever state
+ * the handle holds, so threads that use the pair on one handle must hold their own lock across it
+ * (tts_amd.engine.Engine.session() does; every Python front door goes through it).
+ *
+ * Sharing the GPU.  For batches of up to CUs/2 sentences the BiLSTM recurrences run on a kernel whose
+ * workgroups exchange h every step and must be co-resident, which holds when the handle has the chip
+ * to itself.  When another process or handle occupies CUs (the reference pre-rolls in the parent while
+ * a producer child synthesizes: basic.tts_kokoro_2_play_pause_works.py:34-41,136-146) a bounded wait
+ * runs out, the call re-runs that phase on the streaming BiLSTM kernel (same bits) and the handle
+ * stays on it for the next 64 phases; K82_LSTM_SPLIT_MAX_B=0 in the environment selects the streaming
+ * kernel from the start.  No call fails or returns different samples because the GPU is shared.
+ *
+ * HIP is initialised lazily by k82_create in the calling process (construction inside a
+ * forked/spawned child is fine: basic.tts_kokoro_2_play_pause_works.py:34-41).
  */
 #ifndef K82_H
 #define K82_H
@@ -83,7 +97,9 @@ int k82_finalize(k82_handle* h);
 /* Phase 1 (token rate): ALBERT -> bert_encoder -> DurationEncoder -> LSTM -> duration_proj ->
  * round(sum(sigmoid)/speed).clamp(1).  Keeps the token-rate state inside the handle for
  * k82_decode.
- *   ids      i64[B][Tmax]  host or device; each row is [0, *phoneme ids, 0] then padding
+ *   ids      i64[B][Tmax]  host or device; each row is [0, *phoneme ids, 0] then padding.  Host ids outside
+ *                          [0, n_token) are rejected with K82_EINVAL; device ids cannot be inspected without a
+ *                          copy and are clamped to the table inside the kernels (never an out-of-bounds read)
  *   lens     i32[B]        host; tokens per row including the two pad tokens (2..512)
  *   ref_s    f32[B][256]   host or device; [s_dec(128) | s_pros(128)]
  *   speed    f32[B]        host (NULL = 1.0)
@@ -133,7 +149,9 @@ int k82_pcm16(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* st
 /* Per-kernel-family timing with HIP events on the engine's stream (bench.py roofline leg).
  * enable=1 starts recording for subsequent calls; k82_prof_read synchronises and returns the
  * accumulated milliseconds / launch count / algorithmic FLOPs (or bytes) of family `name`
- * ("conv_mfma", "conv_mfma_c128", "lstm", "instnorm", "attention", "istft", "source") since enable. */
+ * ("conv_mfma", "conv_mfma_2x2", "conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "gather", "source",
+ * "other") since enable.  The name "lstm_fallbacks" returns, in *launches, how many phases this handle has re-run
+ * on the streaming BiLSTM kernel since it was created (see "Sharing the GPU" above). */
 int k82_prof_enable(k82_handle* h, int enable);
 int k82_prof_read(k82_handle* h, const char* name, double* ms, int64_t* launches, double* work);
 
@@ -143,6 +161,14 @@ int k82_prof_read(k82_handle* h, const char* name, double* ms, int64_t* launches
 int k82_debug_enable(k82_handle* h, int enable);
 int k82_debug_info(k82_handle* h, const char* name, int64_t dims[3]);
 int k82_debug_copy(k82_handle* h, const char* name, float* dst);
+
+/* Teacher forcing for parity tests against committed golden vectors (tests/golden/): replaces a stage tensor of the
+ * NEXT k82_decode calls, right after the engine computed it, by host data -- "F0" / "N": f32[1][2F]; "har":
+ * f32[22][120F+1] (magnitude | phase of the source STFT).  Batches of one sentence only; data == NULL removes the
+ * override.  The model integrates F0 into a phase and takes angle() of near-empty STFT bins, so two correct fp32
+ * implementations drift apart downstream of these three tensors (DESIGN.md "numerical conditioning"); with them
+ * pinned, the waveform is comparable sample by sample. */
+int k82_debug_force(k82_handle* h, const char* name, const float* data, int64_t rows, int64_t cols);
 
 /* Stand-alone launch of the hot conv kernel (unit parity tests and kernel benchmarks).
  * y[b][co][t] = out_act( sum_{ci,k} w[co][ci][k] * act(x[b][ci][t + k*dil - pad]) + bias[co] )

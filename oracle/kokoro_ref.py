@@ -162,7 +162,7 @@ class AdainResBlk1d(nn.Module):
         sc = F.interpolate(x, scale_factor=2, mode="nearest") if self.upsample else x
         if self.learned_sc:
             sc = self.conv1x1(sc)
-        return (r + sc) * torch.rsqrt(torch.tensor(2.0))
+        return (r + sc) * torch.rsqrt(torch.tensor(2.0, dtype=r.dtype))
 
 
 class ProsodyPredictor(nn.Module):
@@ -268,14 +268,36 @@ def _fma32(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F32)
 
 
+def sinegen_phase64(f0_lo: np.ndarray, upsample: int = 300, sr: float = 24000.0, harmonics: int = 9):
+    """The same phase in float64 throughout (the fp64 arbitration run, tools/make_golden.py): what the formula
+    means, without the fp32 roundings that the fp32 model -- any implementation of it -- commits on phases of
+    1e4..1e6 rad."""
+    f0_lo = np.asarray(f0_lo, np.float64)
+    n = f0_lo.shape[0]
+    h = np.arange(1, harmonics + 1, dtype=np.float64)
+    rad = np.mod(f0_lo[:, None] * h[None, :] / sr, 1.0)
+    ph = np.cumsum(rad, axis=0) * 2.0 * math.pi * upsample
+    L = n * upsample
+    src = np.maximum((np.arange(L, dtype=np.float64) + 0.5) / upsample - 0.5, 0.0)
+    i0 = np.floor(src).astype(np.int64)
+    lam = src - i0
+    i1 = np.minimum(i0 + 1, n - 1)
+    return (1.0 - lam)[:, None] * ph[i0] + lam[:, None] * ph[i1]
+
+
 def harmonic_source(f0_curve: torch.Tensor, noise: torch.Tensor, lin_w: torch.Tensor, lin_b: torch.Tensor,
                     upsample: int = 300):
     """SourceModuleHnNSF + SineGen with injected noise.  f0_curve [1, 2F]; noise [1, 600F, 9]."""
-    f0_lo = f0_curve[0].detach().numpy().astype(F32)
-    phase = torch.from_numpy(sinegen_phase(f0_lo, upsample))
+    dt = f0_curve.dtype
+    if dt == torch.float64:
+        f0_lo = f0_curve[0].detach().numpy()
+        phase = torch.from_numpy(sinegen_phase64(f0_lo, upsample))
+    else:
+        f0_lo = f0_curve[0].detach().numpy().astype(F32)
+        phase = torch.from_numpy(sinegen_phase(f0_lo, upsample))
     sines = torch.sin(phase) * 0.1
     f0_up = torch.from_numpy(np.repeat(f0_lo, upsample))
-    uv = (f0_up > 10.0).to(torch.float32).unsqueeze(-1)
+    uv = (f0_up > 10.0).to(dt).unsqueeze(-1)
     noise_amp = uv * 0.003 + (1 - uv) * 0.1 / 3
     sw = sines * uv + noise_amp * noise[0]
     har = torch.tanh(F.linear(sw, lin_w, lin_b))          # [600F, 1]
@@ -343,7 +365,7 @@ class Generator(nn.Module):
             # angle() is discontinuous: where |X_k| is at rounding-noise level a last-bit difference
             # of har_source flips the phase by 2*pi.  Stage-wise parity feeds the consumer stages the
             # engine's own [mag | phase] tensor; `har` itself is compared modulo 2*pi by the tests.
-            har = torch.as_tensor(har_override, dtype=torch.float32).reshape(har.shape)
+            har = torch.as_tensor(har_override, dtype=har.dtype).reshape(har.shape)
         if taps is not None:
             taps["sine_waves"] = sw
             taps["har_source"] = har_source
@@ -475,7 +497,8 @@ class KModelRef(nn.Module):
         T = ids_padded.shape[1]
         idx = torch.repeat_interleave(torch.arange(T), pred_dur)
         nF = int(idx.shape[0])
-        aln = torch.zeros((T, nF))
+        dt = self.bert_encoder.weight.dtype               # float32; float64 in the arbitration run (build(..., dtype))
+        aln = torch.zeros((T, nF), dtype=dt)
         aln[idx, torch.arange(nF)] = 1
         aln = aln.unsqueeze(0)
         s = ref_s[:, 128:]
@@ -485,13 +508,14 @@ class KModelRef(nn.Module):
             taps["F0"] = F0_pred
             taps["N"] = N_pred
         if f0_override is not None:
-            F0_pred = torch.as_tensor(f0_override, dtype=torch.float32).reshape(1, -1)
+            F0_pred = torch.as_tensor(f0_override, dtype=dt).reshape(1, -1)
         if n_override is not None:
-            N_pred = torch.as_tensor(n_override, dtype=torch.float32).reshape(1, -1)
+            N_pred = torch.as_tensor(n_override, dtype=dt).reshape(1, -1)
         t_en = self.text_encoder(ids_padded)
         asr = t_en @ aln
         if noise is None:
             noise = torch.zeros((1, nF * 600, 9))
+        noise = noise.to(dt)
         if taps is not None:
             taps["en"] = en
             taps["shared"] = shared
@@ -529,6 +553,10 @@ def counter_noise(seed: int, n_samples: int, harmonics: int = 9) -> np.ndarray:
     return (r * np.cos((F32(2.0) * PI_F * u2).astype(F32)).astype(F32)).astype(F32)
 
 
-def build(config, state_dicts) -> KModelRef:
+def build(config, state_dicts, dtype=torch.float32) -> KModelRef:
+    """dtype=torch.float64: the SAME fp32 parameters evaluated in double precision (module.double(); the harmonic
+    phase in float64 too) -- the arbiter between two fp32 implementations where the model itself is ill-conditioned
+    (DESIGN.md "numerical conditioning").  Inputs (ref_s, noise) are cast by the caller / forward."""
     torch.manual_seed(0)
-    return KModelRef(config).load_state_dicts(state_dicts)
+    m = KModelRef(config).load_state_dicts(state_dicts)
+    return m.double() if dtype == torch.float64 else m

@@ -255,3 +255,28 @@ def test_oracle_reproduces_committed_golden(oracle_model):
     assert np.abs(taps["t_en"].numpy()[0] - g["t_en"]).max() < 1e-4
     assert np.abs(taps["F0"].numpy()[0] - g["F0"]).max() < 5e-2
     assert audio.numel() == g["audio_len"]
+
+
+def test_oracle_fp32_and_fp64_reproduce_committed_T8(oracle_model, synthetic_sds):
+    """tests/golden/synthetic_T8.npz (tools/make_golden.py): the fp32 oracle reproduces its committed durations, F0
+    and waveform on this machine, and the float64 evaluation of the same parameters (the arbiter of the GPU golden
+    tests) reproduces its committed pre-rounding durations and F0 to double-precision noise."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "synthetic_T8.npz"))
+    ids, rs = torch.from_numpy(g["ids"])[None], torch.from_numpy(g["ref_s"])[None]
+    noise = torch.from_numpy(R.counter_noise(int(g["noise_seed"]), int(g["decode_dur"].sum()) * 600))[None]
+    taps = {}
+    audio, pd = oracle_model.forward_with_tokens(ids, rs, 1.0, noise=noise, taps=taps)
+    assert np.array_equal(pd.numpy(), g["pred_dur"])
+    assert np.abs(taps["duration"].numpy() - g["raw32"]).max() < 1e-4
+    assert np.abs(taps["F0"].numpy()[0] - g["F0_32"]).max() < 5e-2
+    assert audio.numel() == g["audio_len"]
+    m64 = R.build(spec.DEFAULT_CONFIG, synthetic_sds, torch.float64)
+    t64 = {}
+    a64, _ = m64.forward_with_tokens(ids, rs.double(), 1.0, noise=noise, pred_dur=g["decode_dur"], taps=t64)
+    assert a64.dtype == torch.float64
+    assert np.abs(t64["duration"].numpy() - g["raw64"]).max() < 1e-9
+    assert np.abs(t64["F0"].numpy()[0] - g["F0_64"]).max() < 1e-7
+    assert np.abs(a64.numpy() - g["audio64"]).max() < 1e-5           # the committed copy is rounded to float32
+    # and the two precisions of the ORACLE disagree free-running by far more than 1e-3: the conditioning finding
+    assert np.abs(audio.numpy() - a64.numpy()).max() > 1e-2

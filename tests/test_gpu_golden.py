@@ -1,0 +1,189 @@
+"""GPU tests against the committed golden vectors tests/golden/synthetic_T{8,64,256,512}.npz (tools/make_golden.py).
+
+Nothing here runs the oracle: the numbers were produced on CPU and committed.  Each vector holds the fp32 oracle's
+results AND the same model evaluated in float64, so where the model itself is ill-conditioned (durations just before
+rounding, the F0 curve the harmonic source integrates, the free-running waveform) the test can ask the only
+meaningful question -- is the engine as close to the fp64 value as the fp32 oracle is? -- instead of asking two fp32
+implementations to agree on noise.  The oracle is unpinned by the reference: this is engine ==
+restatement, measured properly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tts_amd import spec
+from oracle import kokoro_ref as R          # counter_noise only (the numpy twin of the in-kernel generator)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+AUDIO_TOL = 1e-3
+
+
+def _load(T):
+    return np.load(os.path.join(GOLD, f"synthetic_T{T}.npz"))
+
+
+def _snr(ref, x):
+    ref, x = ref.astype(np.float64), x.astype(np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max(((ref - x) ** 2).sum(), 1e-300))
+
+
+def _run(engine, g, forced_curves):
+    ids = g["ids"][None].astype(np.int64)
+    T = ids.shape[1]
+    lens = np.array([T], dtype=np.int32)
+    ref_s = g["ref_s"][None]
+    dec = g["decode_dur"].astype(np.int32)
+    use_forced_dur = not np.array_equal(dec, g["pred_dur"])
+    F = int(dec.sum())
+    noise = R.counter_noise(int(g["noise_seed"]), F * 600)
+    out = {}
+    engine.debug_enable(True)
+    try:
+        with engine.session():
+            pred, nfr = engine.durations(ids, lens, ref_s)                       # the model's own durations first
+            out["pred"], out["raw"] = pred[0].copy(), engine.debug_get("duration")[0, 0, :T].copy()
+            out["stages_T"] = {k: engine.debug_get(k)[0] for k in ("bert_out", "d_en", "d", "dur_lstm")}
+            if use_forced_dur:
+                pred2, nfr = engine.durations(ids, lens, ref_s, forced_dur=dec[None])
+                assert np.array_equal(pred2[0], dec)
+            assert int(nfr[0]) == F
+            if forced_curves:
+                engine.debug_force("F0", g["F0_32"])
+                engine.debug_force("N", g["N_32"])
+                engine.debug_force("har", g["har32"])
+            audio, off = engine.decode(noise=noise)
+            out["audio"] = audio.copy()
+            out["F0"], out["N"] = engine.debug_get("F0")[0, 0, :2 * F].copy(), engine.debug_get("N")[0, 0, :2 * F].copy()
+            out["stages_F"] = {k: engine.debug_get(k)[0] for k in (
+                "en", "shared", "t_en", "asr", "dec_encode", "dec_out", "gen0_noise_conv", "gen0_xsource", "gen0_out",
+                "gen1_xsource", "gen1_out", "conv_post")}
+    finally:
+        for k in ("F0", "N", "har"):
+            engine.debug_force(k, None)
+        engine.debug_enable(False)
+    out["T"], out["F"] = T, F
+    return out
+
+
+def _check_durations(g, r, T):
+    """Integer durations bit-exact; pre-rounding values no further from the fp64 arbiter than the fp32 oracle is
+    (x2 + a floor of 1e-4: one fp32 ulp of a sum of 50 sigmoids ~ 25 is 2e-6, the LSTM stack amplifies ~50x)."""
+    assert np.array_equal(r["pred"], g["pred_dur"]), (r["pred"], g["pred_dur"])
+    err_e = float(np.abs(r["raw"].astype(np.float64) - g["raw64"]).max())
+    err_o = float(np.abs(g["raw32"].astype(np.float64) - g["raw64"]).max())
+    margin = float(np.abs((g["raw64"] % 1.0) - 0.5).min())
+    print(f"T{T}: raw duration |engine-fp64| {err_e:.2e}, |oracle32-fp64| {err_o:.2e}, min fp64 rounding margin {margin:.2e}")
+    assert err_e <= 2.0 * err_o + 1e-4, (err_e, err_o)
+    # every token whose fp64 value is further from a rounding boundary than the engine's own error must round alike
+    far = np.abs((g["raw64"] % 1.0) - 0.5) > err_e
+    want = np.maximum(np.rint(g["raw64"]), 1).astype(np.int64)
+    assert np.array_equal(r["pred"][far], want[far])
+
+
+def _lens_of(name, T, F):
+    return {"bert_out": T, "d_en": T, "d": T, "dur_lstm": T, "t_en": T, "en": F, "shared": F, "asr": F, "dec_encode": F,
+            "dec_out": 2 * F, "gen0_noise_conv": 20 * F, "gen0_xsource": 20 * F, "gen0_out": 20 * F,
+            "gen1_xsource": 120 * F + 1, "gen1_out": 120 * F + 1, "conv_post": 120 * F + 1}[name]
+
+
+ROWS = {"bert_out": 768, "d_en": 512, "d": 640, "dur_lstm": 512, "t_en": 512, "en": 640, "shared": 512, "asr": 512,
+        "dec_encode": 1024, "dec_out": 512, "gen0_noise_conv": 256, "gen0_xsource": 256, "gen0_out": 256,
+        "gen1_xsource": 128, "gen1_out": 128, "conv_post": 22}
+
+
+def _check_checksums(g, r, names, tol):
+    """Committed per-stage checksums of the fp32 oracle (sum, sum|x|, max|x|): the engine's tensors must reproduce
+    sum|x| and max|x| to ``tol`` relative (plain sums cancel and are compared against sum|x|)."""
+    T, F = r["T"], r["F"]
+    for name in names:
+        got = {**r["stages_T"], **r["stages_F"]}[name][:ROWS[name], :_lens_of(name, T, F)].astype(np.float64)
+        s, sa, mx = g["sum_" + name]
+        assert abs(np.abs(got).sum() - sa) <= tol * sa, (name, np.abs(got).sum(), sa)
+        assert abs(got.sum() - s) <= tol * sa, (name, got.sum(), s)
+        assert abs(np.abs(got).max() - mx) <= 10 * tol * max(mx, 1.0), (name, np.abs(got).max(), mx)
+
+
+@pytest.mark.parametrize("T", [8, 64])
+def test_golden_teacher_forced_waveform(engine, T):
+    """Short vectors: durations bit-exact; with F0 / N / har pinned to the committed oracle tensors the engine's
+    waveform meets the north-star bar (max-abs <= 1e-3) against the committed oracle waveform, sample by sample; every
+    stage checksum downstream of the pinned tensors to 2e-4."""
+    g = _load(T)
+    r = _run(engine, g, forced_curves=True)
+    _check_durations(g, r, T)
+    assert r["audio"].size == int(g["audio_len"])
+    err = float(np.abs(r["audio"] - g["audio32"]).max())
+    print(f"T{T}: teacher-forced waveform max-abs vs committed oracle audio: {err:.2e}")
+    assert err <= AUDIO_TOL, err
+    _check_checksums(g, r, ("bert_out", "d_en", "t_en", "en", "asr", "shared", "dec_encode", "dec_out", "gen0_noise_conv",
+                            "gen0_xsource", "gen0_out", "gen1_xsource", "gen1_out", "conv_post"), 2e-4)
+    _check_checksums(g, r, ("d", "dur_lstm"), 2e-3)
+
+
+@pytest.mark.parametrize("T", [8, 64, 256, 512])
+def test_golden_free_running_against_fp64_arbiter(engine, T):
+    """No teacher forcing.  The engine's F0 / N curves must be as close to the float64 evaluation of the model as the
+    fp32 oracle's own curves are (x2 + 2e-5 of the range), and so must the waveform (SNR against fp64 no more than 3 dB below the fp32
+    oracle's SNR against fp64): the free-running sample-wise gap between two fp32 implementations is the model's
+    conditioning, not an engine error -- the fp32 oracle itself sits 0.15-0.77 max-abs from the fp64 waveform."""
+    g = _load(T)
+    r = _run(engine, g, forced_curves=False)
+    _check_durations(g, r, T)
+    for name in ("F0", "N"):
+        ref64 = g[name + "_64"]
+        e_eng = float(np.abs(r[name].astype(np.float64) - ref64).max())
+        e_orc = float(np.abs(g[name + "_32"].astype(np.float64) - ref64).max())
+        scale = float(np.abs(ref64).max())
+        print(f"T{T}: {name} |engine-fp64| {e_eng:.2e}, |oracle32-fp64| {e_orc:.2e} (max |{name}| {scale:.1f})")
+        # x2 of the oracle's own distance plus a floor of 2e-5 of the curve's range (measured: T8 3.0x / T64 1.0x /
+        # T256 1.6x / T512 0.07x -- at 510 phonemes the fp32 ORACLE is 0.29 Hz from fp64, the engine 0.02 Hz)
+        assert e_eng <= 2.0 * e_orc + 2e-5 * scale, (name, e_eng, e_orc)
+        assert e_eng <= 5e-4 * max(scale, 1.0), (name, e_eng, scale)          # relative 5e-4 against the arbiter
+    st = int(g["audio_stride"])
+    a = r["audio"][::st]
+    assert r["audio"].size == int(g["audio_len"]) and a.size == g["audio64"].size
+    snr_e, snr_o = _snr(g["audio64"], a), _snr(g["audio64"], g["audio32"])
+    mx_e, mx_o = float(np.abs(a - g["audio64"]).max()), float(np.abs(g["audio32"] - g["audio64"]).max())
+    print(f"T{T}: free-running vs fp64: engine SNR {snr_e:.1f} dB (max-abs {mx_e:.3f}); fp32 oracle SNR {snr_o:.1f} dB (max-abs {mx_o:.3f})")
+    assert snr_e >= snr_o - 3.0, (snr_e, snr_o)
+    # token-rate stages are upstream of every ill-conditioned step: checksums hold free-running too
+    _check_checksums(g, r, ("bert_out", "d_en", "t_en"), 2e-4)
+
+
+def test_free_running_waveform_meets_the_bar_on_calm_weights():
+    """A second synthetic weight set (spec.synthetic_state_dicts(lstm_gain=1, f0_gain=1, f0_bias=0)): duration-branch
+    LSTMs at default scale and an F0 head that stays below the 10 Hz voicing threshold, so nothing is integrated into
+    a phase.  There the engine must meet max-abs <= 1e-3 against the fp32 oracle FREE-RUNNING -- no forced curves --
+    which shows the teacher forcing elsewhere compensates the model's conditioning, not an engine defect."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    import torch
+    from tts_amd.engine import Engine
+    sds = spec.synthetic_state_dicts(0, lstm_gain=1.0, f0_gain=1.0, f0_bias=0.0)
+    model = R.build(spec.DEFAULT_CONFIG, sds)
+    eng = Engine(sds)
+    try:
+        rng = np.random.default_rng(77)
+        id_lists = [rng.integers(1, 178, size=n).tolist() for n in (9, 40, 23)]
+        pack = spec.synthetic_voice_pack(1)
+        ref_s = np.stack([pack[len(x) - 1, 0] for x in id_lists]).astype(np.float32)
+        ids, lens = eng.pack(id_lists)
+        eng.debug_enable(True)
+        with eng.session():
+            pred, nfr = eng.durations(ids, lens, ref_s)
+            noise = np.concatenate([R.counter_noise(300 + b, int(nfr[b]) * 600) for b in range(3)])
+            audio, off = eng.decode(noise=noise)
+            f0 = eng.debug_get("F0")
+        assert float(np.abs(f0).max()) < 10.0, "the calm set must be unvoiced everywhere"
+        for b, x in enumerate(id_lists):
+            t = torch.tensor([[0] + x + [0]])
+            a_ref, pd = model.forward_with_tokens(t, torch.from_numpy(ref_s[b:b + 1].copy()), 1.0,
+                                                  noise=torch.from_numpy(noise.reshape(-1, 9)[off[b]:off[b + 1]][None].copy()))
+            assert np.array_equal(pd.numpy(), pred[b, :lens[b]])
+            err = float(np.abs(audio[off[b]:off[b + 1]] - a_ref.numpy()).max())
+            print(f"calm weights, sentence {b}: free-running max-abs {err:.2e}")
+            assert err <= AUDIO_TOL, (b, err)
+    finally:
+        eng.close()

@@ -14,7 +14,7 @@ K82_OK, K82_ENOSPC = 0, -28
 EXPORTS = (
     "k82_create", "k82_destroy", "k82_last_error", "k82_set_tensor", "k82_finalize", "k82_durations",
     "k82_decode", "k82_synthesize", "k82_pcm16", "k82_set_precision", "k82_prof_enable", "k82_prof_read", "k82_debug_enable",
-    "k82_debug_info", "k82_debug_copy", "k82_op_conv1d",
+    "k82_debug_info", "k82_debug_copy", "k82_debug_force", "k82_op_conv1d",
 )
 
 
@@ -66,6 +66,7 @@ def load():
     lib.k82_debug_enable.argtypes = [vp, i32]
     lib.k82_debug_info.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     lib.k82_debug_copy.argtypes = [vp, C.c_char_p, vp]
+    lib.k82_debug_force.argtypes = [vp, C.c_char_p, vp, i64, i64]
     lib.k82_op_conv1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, i32,
                                   C.POINTER(C.c_float)]
     for n in EXPORTS:

@@ -79,9 +79,9 @@ void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, 
                            const float* gb, int gbstride, int goff, float leaky, hipStream_t s);
 void launch_albert_embed(const int64_t* ids, int Tmax, const float* word, const float* pos, const float* type0,
                          const float* lnw, const float* lnb, float eps, float* y, long ybs, int ypitch,
-                         LenSpec ls, int B, hipStream_t s);
+                         LenSpec ls, int B, int n_token, hipStream_t s);
 void launch_embed(const int64_t* ids, int Tmax, const float* emb, int C, float* y, long ybs, int ypitch,
-                  LenSpec ls, int B, hipStream_t s);
+                  LenSpec ls, int B, int n_token, hipStream_t s);
 // qkv [B][3*H*64][pitch] -> ctx [B][H*64][pitch]
 void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long cbs, int cpitch,
                       LenSpec ls, int heads, int B, int Tmax, hipStream_t s);
@@ -89,7 +89,12 @@ void launch_attention(const float* qkv, long qbs, int qpitch, float* ctx, long c
 void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch,
                  LenSpec ls, int B, hipStream_t s);
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
-                       int B, float* hx, int* err, int cus, hipStream_t s);
+                       int B, float* hx, int* err, int cus, int spin_limit, hipStream_t s);
+// The split kernel is correct only while all four workgroups of a recurrence are resident together, which the launcher
+// can promise only if the handle has the chip to itself.  A second process or a second handle on the same GPU
+// (basic.tts_kokoro_2_play_pause_works.py:34-41,136-146 pre-rolls in the parent while the producer child synthesizes)
+// can hold the CUs a partner needs: the bounded spin (spin_limit polls) then sets *err, every wave leaves, and the
+// engine re-runs the phase on lstm_kernel -- bit-identical by construction -- and stays on it for a while.
 // The split recurrence is used up to CUs / 2 sentences (four rounds of the grid).  Its four workgroups per (direction, sentence) are adjacent in
 // dispatch order; with more than CUs / 8 sentences the grid runs in rounds (in-order dispatch: at most one recurrence
 // straddles the residency boundary and gets its missing parts as soon as any complete one finishes).  Per

@@ -229,10 +229,13 @@ void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, 
 __global__ __launch_bounds__(64) void albert_embed_kernel(const int64_t* ids, int Tmax, const float* word,
                                                          const float* pos, const float* type0, const float* lnw,
                                                          const float* lnb, float eps, float* y, long ybs, int ypitch,
-                                                         LenSpec ls) {
+                                                         LenSpec ls, int n_token) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
     if (t >= ls.len(b)) return;
-    const float* wv = word + (long)ids[(long)b * Tmax + t] * 128;
+    // ids that live on the device cannot be validated by the host: an id outside the table reads row 0 / n_token-1
+    // instead of faulting (host ids are rejected with K82_EINVAL before any launch)
+    const int64_t id = min(max(ids[(long)b * Tmax + t], (int64_t)0), (int64_t)(n_token - 1));
+    const float* wv = word + id * 128;
     const float* pv = pos + (long)t * 128;
     float s = 0.f;
     for (int c = 0; c < 128; ++c) s += (wv[c] + type0[c]) + pv[c];
@@ -248,22 +251,22 @@ __global__ __launch_bounds__(64) void albert_embed_kernel(const int64_t* ids, in
 }
 void launch_albert_embed(const int64_t* ids, int Tmax, const float* word, const float* pos, const float* type0,
                          const float* lnw, const float* lnb, float eps, float* y, long ybs, int ypitch, LenSpec ls,
-                         int B, hipStream_t s) {
+                         int B, int n_token, hipStream_t s) {
     hipLaunchKernelGGL(albert_embed_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, ids, Tmax, word, pos, type0,
-                       lnw, lnb, eps, y, ybs, ypitch, ls);
+                       lnw, lnb, eps, y, ybs, ypitch, ls, n_token);
 }
 
 __global__ __launch_bounds__(64) void embed_kernel(const int64_t* ids, int Tmax, const float* emb, int C, float* y,
-                                                  long ybs, int ypitch, LenSpec ls) {
+                                                  long ybs, int ypitch, LenSpec ls, int n_token) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
     if (t >= ls.len(b)) return;
-    const float* e = emb + (long)ids[(long)b * Tmax + t] * C;
+    const float* e = emb + min(max(ids[(long)b * Tmax + t], (int64_t)0), (int64_t)(n_token - 1)) * C;
     float* yc = y + (long)b * ybs + t;
     for (int c = 0; c < C; ++c) yc[(long)c * ypitch] = e[c];
 }
 void launch_embed(const int64_t* ids, int Tmax, const float* emb, int C, float* y, long ybs, int ypitch, LenSpec ls,
-                  int B, hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, ids, Tmax, emb, C, y, ybs, ypitch, ls);
+                  int B, int n_token, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, ids, Tmax, emb, C, y, ybs, ypitch, ls, n_token);
 }
 
 // ------------------------------------------------------------------ attention (row a5)
@@ -439,7 +442,8 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, i
 // recurrences; each sentence keeps its own chains, so the bits do not depend on NS.
 template <int NS>
 __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, long gbs, int gpitch, const float* whh, float* y,
-                                                           long ybs, int ypitch, LenSpec ls, int B, float* hx, int* err) {
+                                                           long ybs, int ypitch, LenSpec ls, int B, float* hx, int* err,
+                                                           int spin_limit) {
     __shared__ __attribute__((aligned(16))) float hbuf[NS][256];
     __shared__ float2 part[NS][4][2][64];
     __shared__ int dead;
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, lon
                     hw[n] = __hip_atomic_load(&H[((s & 1) * NS + n) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     all = all && (s >= Tn[n] || (unsigned)(hw[n] >> 32) == (unsigned)(s + 1));
                 }
-                if (!all && ++spins > (1 << 18)) { dead = 1; *err = 1; break; }
+                if (!all && ++spins > spin_limit) { dead = 1; *err = 1; break; }
             } while (!all);
 #pragma unroll
             for (int n = 0; n < NS; ++n) hbuf[n][tid] = __uint_as_float((unsigned)hw[n]);
@@ -550,14 +554,14 @@ void launch_lstm(const float* gx, long gbs, int gpitch, const float* whh, float*
 // hx: exchange buffer of 8-byte (value, step) words [ceil(B / NS)][2 dirs][2 parities][NS][256], i.e. 2048 floats per
 // sentence with B rounded up to 4, zeroed here; err: one device int (sticky); cus: CUs of the device
 void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, float* y, long ybs, int ypitch, LenSpec ls,
-                       int B, float* hx, int* err, int cus, hipStream_t s) {
+                       int B, float* hx, int* err, int cus, int spin_limit, hipStream_t s) {
     (void)hipMemsetAsync(hx, 0, (size_t)((B + 3) / 4 * 4) * 2048 * sizeof(float), s);      // step tags start at 0
     if (8 * B <= cus)
-        hipLaunchKernelGGL(lstm_split_kernel<1>, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err);
+        hipLaunchKernelGGL(lstm_split_kernel<1>, dim3(8 * B), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err, spin_limit);
     else if (8 * ((B + 1) / 2) <= cus)
-        hipLaunchKernelGGL(lstm_split_kernel<2>, dim3(8 * ((B + 1) / 2)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err);
+        hipLaunchKernelGGL(lstm_split_kernel<2>, dim3(8 * ((B + 1) / 2)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err, spin_limit);
     else
-        hipLaunchKernelGGL(lstm_split_kernel<4>, dim3(8 * ((B + 3) / 4)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err);
+        hipLaunchKernelGGL(lstm_split_kernel<4>, dim3(8 * ((B + 3) / 4)), dim3(512), 0, s, gx, gbs, gpitch, whh, y, ybs, ypitch, ls, B, hx, err, spin_limit);
 }
 
 // ------------------------------------------------------------------------ small helpers

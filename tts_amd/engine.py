@@ -7,7 +7,9 @@ wrap ``create`` in ``try/except Exception`` and fall back: speech7.py:126-133).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -51,6 +53,12 @@ class Engine:
 
     def __init__(self, state_dicts, config=None, device=0, precision="fp32"):
         self.lib = _lib.load()
+        # k82_durations leaves the token-rate state of ITS batch inside the handle for k82_decode, so the pair is one
+        # critical section: every caller that may share this Engine with another thread (both front doors do, and the
+        # reference runs two pool threads on one Kokoro object: epubviewer_06_latest_1_nov_2025_theme.py:407,692,715)
+        # runs the pair inside ``with engine.session():``.  Re-entrant, so durations()/decode() take it themselves too.
+        self._lock = threading.RLock()
+        self._pending = None               # (owner thread id, n_frames) of the durations call a decode may follow
         self.config = config or spec.DEFAULT_CONFIG
         self.device = device
         self.h = C.c_void_p()
@@ -94,6 +102,13 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------ the hot path
+    @contextlib.contextmanager
+    def session(self):
+        """Exclusive use of the handle across a durations() -> decode() pair (or any sequence of calls whose
+        results depend on each other: set_precision / debug taps).  Other threads block at their own session()."""
+        with self._lock:
+            yield self
+
     @staticmethod
     def pack(id_lists):
         """list of per-sentence id lists (WITHOUT pads) -> (ids i64[B,Tmax] with [0,*ids,0], lens i32[B])."""
@@ -119,40 +134,54 @@ class Engine:
         fd = None if forced_dur is None else np.ascontiguousarray(forced_dur, dtype=np.int32).reshape(B, tmax)
         pred = np.zeros((B, tmax), dtype=np.int32)
         nfr = np.zeros((B,), dtype=np.int64)
-        self._check(self.lib.k82_durations(self.h, _ptr(ids), _ptr(lens), B, tmax, _ptr(ref_s), _ptr(sp), _ptr(fd),
-                                           _ptr(pred), _ptr(nfr), _ptr(stream)))
-        self._last_nfr = nfr
+        with self._lock:
+            self._pending = None
+            self._check(self.lib.k82_durations(self.h, _ptr(ids), _ptr(lens), B, tmax, _ptr(ref_s), _ptr(sp), _ptr(fd),
+                                               _ptr(pred), _ptr(nfr), _ptr(stream)))
+            self._pending = (threading.get_ident(), nfr)
         return pred, nfr
 
     def decode(self, noise=None, seeds=None, out=None, stream=None):
-        """Phase 2 for the batch of the last ``durations`` call.
+        """Phase 2 for the batch of the preceding ``durations`` call OF THIS THREAD.
 
         ``out``: None -> host numpy buffer; or (device_ptr, capacity_floats).  Returns
         (audio, offsets i64[B+1]); audio is the numpy buffer or None when ``out`` was given.
+        Raises RuntimeError when another thread's durations() came in between (the pair was not run inside
+        ``with engine.session():``) instead of decoding that other batch.
         """
-        nfr = self._last_nfr
-        total = int(nfr.sum()) * spec.FRAME_SAMPLES
-        nz = K = None
-        if noise is not None:
-            nz = np.ascontiguousarray(noise, dtype=np.float32)
-            assert nz.size == total * 9, (nz.size, total * 9)
-        if seeds is not None:
-            K = np.ascontiguousarray(seeds, dtype=np.uint64)
-        ns = _lib.K82Noise(noise=_ptr(nz), seeds=_ptr(K))
-        off = np.zeros((nfr.shape[0] + 1,), dtype=np.int64)
-        if out is None:
-            audio = _host_buffer(total)
-            self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(audio), total, _ptr(off), _ptr(stream)))
-            return audio, off
-        ptr, cap = out
-        self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(ptr), int(cap), _ptr(off), _ptr(stream)))
-        return None, off
+        with self._lock:
+            pend = self._pending
+            if pend is None or pend[0] != threading.get_ident():
+                raise RuntimeError("Engine.decode: the handle does not hold this thread's durations() state -- run the "
+                                   "durations()/decode() pair inside `with engine.session():` when threads share an Engine")
+            nfr = pend[1]
+            B = nfr.shape[0]
+            total = int(nfr.sum()) * spec.FRAME_SAMPLES
+            nz = K = None
+            if noise is not None:
+                nz = np.ascontiguousarray(noise, dtype=np.float32)
+                if nz.size != total * 9:
+                    raise ValueError(f"noise holds {nz.size} values, the batch needs {total * 9}")
+            if seeds is not None:
+                K = np.ascontiguousarray(seeds, dtype=np.uint64)
+                if K.shape != (B,):
+                    raise ValueError(f"seeds has shape {K.shape}, the batch has {B} sentences")
+            ns = _lib.K82Noise(noise=_ptr(nz), seeds=_ptr(K))
+            off = np.zeros((B + 1,), dtype=np.int64)
+            if out is None:
+                audio = _host_buffer(total)
+                self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(audio), total, _ptr(off), _ptr(stream)))
+                return audio, off
+            ptr, cap = out
+            self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(ptr), int(cap), _ptr(off), _ptr(stream)))
+            return None, off
 
     def synthesize(self, id_lists, ref_s, speed=None, noise=None, seeds=None):
-        """list of id lists -> list of f32 audio arrays (+ pred_dur)."""
+        """list of id lists -> list of f32 audio arrays (+ pred_dur).  Atomic with respect to other threads."""
         ids, lens = self.pack(id_lists)
-        pred, _ = self.durations(ids, lens, ref_s, speed)
-        audio, off = self.decode(noise=noise, seeds=seeds)
+        with self.session():
+            pred, _ = self.durations(ids, lens, ref_s, speed)
+            audio, off = self.decode(noise=noise, seeds=seeds)
         return [audio[off[b]:off[b + 1]] for b in range(len(id_lists))], pred
 
     def pcm16(self, audio):
@@ -180,6 +209,16 @@ class Engine:
         out = np.empty(tuple(int(d) for d in dims), dtype=np.float32)
         self._check(self.lib.k82_debug_copy(self.h, name.encode(), _ptr(out)))
         return out
+
+    def debug_force(self, name, data=None):
+        """k82_debug_force: pin stage ``name`` ("F0", "N": f32[2F]; "har": f32[22, 120F+1]) of the next decode()
+        calls to ``data`` (None removes the override).  Single-sentence batches; parity tests only."""
+        if data is None:
+            self._check(self.lib.k82_debug_force(self.h, name.encode(), None, 0, 0))
+            return
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        a = a.reshape(1, -1) if a.ndim == 1 else a
+        self._check(self.lib.k82_debug_force(self.h, name.encode(), _ptr(a), a.shape[0], a.shape[1]))
 
     def op_conv1d(self, x, w, bias=None, dil=1, act=0, slope=1.0, alpha=None, iters=1):
         x = np.ascontiguousarray(x, np.float32)

@@ -31,6 +31,17 @@ _engine_lock = threading.Lock()
 _engines = {}
 
 
+def _content_seed(ids) -> int:
+    """Seed of the harmonic source's noise for one chunk: a hash of its token ids (FNV-1a, 64 bit).  kokoro_onnx
+    draws the noise inside the graph (Random* nodes) and exposes no seed; keying ours by content makes ``create``
+    a pure function of its arguments -- the same sentence gives the same samples whichever thread, batch or call
+    order it is synthesized in (what the concurrent-create test pins)."""
+    h = 0xcbf29ce484222325
+    for v in ids:
+        h = ((h ^ (int(v) & 0xffff)) * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
 def _shared_engine(key, state_dicts_fn, config, device):
     """One Engine (one copy of the weights) per (checkpoint, device) per process, built lazily in
     the process that first synthesizes (never at import): child processes that construct their
@@ -71,8 +82,6 @@ class Kokoro:
         if precision != "fp32":          # "bf16" / "bf16x3": k82_set_precision (no counterpart in the reference)
             self.engine.set_precision(precision)
         self.synth = BatchSynthesizer(self.engine)
-        self._seed = 0
-        self._seed_lock = threading.Lock()
 
     @classmethod
     def from_session(cls, session, voices_path: str):
@@ -113,9 +122,7 @@ class Kokoro:
             id_lists += ids
             rows += rs
             owner += [ti] * len(ids)
-        with self._seed_lock:
-            seeds = [self._seed + i for i in range(len(id_lists))]
-            self._seed += len(id_lists)
+        seeds = [_content_seed(ids) for ids in id_lists]
         res = self.synth.synthesize(id_lists, rows, speeds=[float(speed)] * len(id_lists), seeds=seeds)
         parts = [[] for _ in texts]
         for i, ti in enumerate(owner):
@@ -151,15 +158,13 @@ class KModel:
             self.config, self.vocab = cfg, cfg.get("vocab") or dict(spec.DEFAULT_VOCAB)
             self.engine = _shared_engine(os.path.abspath(model), lambda: W.load_pth(model), cfg, device)
         self.context_length = self.config["plbert"]["max_position_embeddings"]
-        self._seed = 0
 
     def forward(self, phonemes: str, ref_s, speed: float = 1, return_output: bool = False):
         import torch
         ids = [self.vocab[p] for p in phonemes if p in self.vocab]
         assert len(ids) + 2 <= self.context_length, (len(ids) + 2, self.context_length)
         rs = np.asarray(ref_s.detach().cpu().numpy() if hasattr(ref_s, "detach") else ref_s, np.float32).reshape(1, 256)
-        audios, pred = self.engine.synthesize([ids], rs, speed=float(speed), seeds=[self._seed])
-        self._seed += 1
+        audios, pred = self.engine.synthesize([ids], rs, speed=float(speed), seeds=[_content_seed(ids)])
         audio = torch.from_numpy(audios[0].copy())
         pd = torch.from_numpy(pred[0, :len(ids) + 2].astype(np.int64))
         return Output(audio=audio, pred_dur=pd) if return_output else audio
@@ -245,7 +250,6 @@ class KPipeline:
         rows = [T.style_row(pack, len(ids), "kpipeline") for ids in id_lists]
         synth = BatchSynthesizer(self.model.engine)
         res = synth.synthesize(id_lists, rows, speeds=[float(speed)] * len(items),
-                               seeds=[self.model._seed + i for i in range(len(items))])
-        self.model._seed += len(items)
+                               seeds=[_content_seed(ids) for ids in id_lists])
         for i, (gs, ps) in enumerate(items):
             yield Result(gs, ps, torch.from_numpy(res[i][0]), torch.from_numpy(res[i][1].astype(np.int64)))

@@ -77,13 +77,18 @@ class BatchSynthesizer:
 
     def _run(self, id_lists, ref_rows, speeds, seeds, out, where):
         ids, lens = self.engine.pack(id_lists)
-        pred, nfr = self.engine.durations(ids, lens, np.stack(ref_rows), speed=np.asarray(speeds, np.float32))
-        if int(nfr.sum()) > self.frame_budget and len(id_lists) > 1:       # bound the frame-rate workspace
+        # the durations -> decode pair shares state inside the handle: one critical section per batch, so two threads
+        # on one engine (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715) interleave whole batches, never halves
+        with self.engine.session():
+            pred, nfr = self.engine.durations(ids, lens, np.stack(ref_rows), speed=np.asarray(speeds, np.float32))
+            split = int(nfr.sum()) > self.frame_budget and len(id_lists) > 1       # bound the frame-rate workspace
+            if not split:
+                audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
+        if split:
             h = len(id_lists) // 2
             self._run(id_lists[:h], ref_rows[:h], speeds[:h], seeds[:h], out, where[:h])
             self._run(id_lists[h:], ref_rows[h:], speeds[h:], seeds[h:], out, where[h:])
             return
-        audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
         for k, w in enumerate(where):
             out[w] = (audio[off[k]:off[k + 1]], pred[k, :lens[k]].copy())     # views of the batch buffer: no second copy
 
