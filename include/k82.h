@@ -144,6 +144,19 @@ int k82_set_precision(k82_handle* h, int mode);
  * (basic.tts_kokoro_2_play_pause_works.py:25).  src/dst host or device. */
 int k82_pcm16(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* stream);
 
+/* k82_pcm16 for callers that cannot allocate.  No counterpart in the reference: it exists for callers that must
+ * not reach hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments and result as k82_pcm16 (bit-identical output), but the device staging that k82_pcm16 takes from
+ * the handle's workspace arena (which may grow) is a fixed static device array inside libk82.so:
+ *   - at most K82_PCM16_STATIC_MAX samples per call, else K82_EINVAL and nothing is written;
+ *   - the call performs no hipMalloc / hipFree / arena growth; the array's address is resolved once per device in
+ *     k82_create;
+ *   - every GPU the library runs on holds its own 24 MiB copy until the process ends; all handles of a process on
+ *     one GPU share that GPU's copy: calls are serialised per GPU inside the library, and the array keeps the last
+ *     call's contents (each call overwrites exactly the [0, n) prefix it then reads). */
+#define K82_PCM16_STATIC_MAX (4 * 1024 * 1024)
+int k82_pcm16_static(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* stream);
+
 /* ---- measurement and test hooks (no counterpart in the reference) ---------------------- */
 
 /* Per-kernel-family timing with HIP events on the engine's stream (bench.py roofline leg).

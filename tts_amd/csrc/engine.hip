@@ -36,6 +36,18 @@ inline int ru(int a, int m) { return (a + m - 1) / m * m; }
 
 std::string g_create_error;
 
+// ---- k82_pcm16_static: the one entry point that allocates nothing (include/k82.h) ------------------------------
+// Staging for host -> device -> host conversion lives in a file-scope device array instead of the workspace arena.
+// Every GPU the library runs on holds its own copy of the array at its own address until the process ends; host
+// code never uses the array's NAME as an address (that is a host-side stand-in) -- it asks the runtime once per
+// device, with that device current, and keeps the answer here.
+constexpr int64_t kPcmStaticMax = (int64_t)4 << 20;                  // samples per call: 16 MiB of float + 8 MiB of int16
+constexpr size_t kPcmStaticBytes = (size_t)kPcmStaticMax * (sizeof(float) + sizeof(int16_t));
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu[kMaxDevices];                                 // calls on one GPU share that GPU's array
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_scratch_init_mu;
+
 // grow-only chunked device arena: no hipMalloc in steady state
 // Grow-only bump allocator for activations.  A pass (one k82_durations / k82_decode call) that outgrows the
 // arena adds chunks on demand; the next reset() folds them into ONE chunk sized for the largest pass seen, so
@@ -100,6 +112,22 @@ struct Arena {
     }
 };
 
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kPcmStaticBytes];
+namespace {
+// device address of `scratch` on the CURRENT device (looked up once per device)
+void* scratch_address(int device) {
+    REQUIRE(device >= 0 && device < kMaxDevices, K82_EINVAL, "device index beyond the static scratch table");
+    std::lock_guard<std::mutex> lk(g_scratch_init_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        REQUIRE(p != nullptr, K82_EHIP, "hipGetSymbolAddress returned no address for the static scratch array");
+        g_scratch_ptr[device] = p;
+    }
+    return g_scratch_ptr[device];
+}
+
 struct HostT { std::vector<float> v; std::vector<int64_t> shape; };
 
 struct ConvW {
@@ -152,6 +180,8 @@ struct k82_handle {
     float *lin_w, *lin_b; ConvW nconv0, nconv1, ups0, ups1, conv_post;
     ResBlock1W nres[2], rb[6];
     float *sfc_pros_w, *sfc_pros_b, *sfc_dec_w, *sfc_dec_b; int Gp = 0, Gd = 0;
+
+    unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (k82_pcm16_static)
 
     // ---- workspace + phase-1 state
     Arena aT, aF;
@@ -1140,6 +1170,7 @@ int k82_create(const k82_config* cfg, int device, k82_handle** out) {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
         REQUIRE(source_init_constants() == 0, K82_EHIP, "hipMemcpyToSymbol failed");
+        h->scratch = (unsigned char*)scratch_address(device);      // set-up time, device current: never on the no-alloc path
         *out = h;
         return K82_OK;
     } catch (const K82Error& e) {
@@ -1226,6 +1257,30 @@ int k82_pcm16(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* st
         launch_pcm16(s, d, n, h->st);
         if (!ddev) HIPCHK(hipMemcpyAsync(dst, d, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
+    });
+}
+
+int k82_pcm16_static(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* stream) {
+    return guarded(h, stream, [&] {
+        REQUIRE(src && dst && n >= 0, K82_EINVAL, "bad k82_pcm16_static arguments");
+        REQUIRE(n <= kPcmStaticMax, K82_EINVAL, "k82_pcm16_static converts at most " + std::to_string(kPcmStaticMax) +
+                                                    " samples per call (static staging buffer); got " + std::to_string(n));
+        REQUIRE(h->scratch, K82_ESTATE, "static scratch address was not resolved at k82_create");
+        if (n == 0) return;
+        const bool sdev = k82_handle::is_device_ptr(src), ddev = k82_handle::is_device_ptr(dst);
+        std::lock_guard<std::mutex> lk(g_scratch_mu[h->device]);      // other handles of this process on this GPU
+        float* sf = (float*)h->scratch;                               // [0, 16 MiB): float staging
+        int16_t* sd = (int16_t*)(h->scratch + (size_t)kPcmStaticMax * sizeof(float));   // then the int16 staging
+        const float* s = src;
+        if (!sdev) {
+            HIPCHK(hipMemcpyAsync(sf, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->st));
+            s = sf;
+        }
+        int16_t* d = ddev ? dst : sd;
+        launch_pcm16(s, d, n, h->st);
+        if (!ddev) HIPCHK(hipMemcpyAsync(dst, d, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        HIPCHK(hipGetLastError());
     });
 }
 

@@ -190,6 +190,17 @@ class Engine:
         self._check(self.lib.k82_pcm16(self.h, _ptr(a), _ptr(out), a.size, None))
         return out
 
+    def pcm16_static(self, audio, out=None):
+        """k82_pcm16_static: the same conversion without any allocation on the device side (static staging array,
+        at most ``K82_PCM16_STATIC_MAX`` samples per call).  ``out``: optional preallocated int16 array."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        if out is None:
+            out = np.empty(a.shape, dtype=np.int16)
+        if out.dtype != np.int16 or out.size < a.size or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous int16 array of at least audio.size elements")
+        self._check(self.lib.k82_pcm16_static(self.h, _ptr(a), _ptr(out), a.size, None))
+        return out[:a.size] if out.ndim == 1 else out
+
     # ------------------------------------------------------------------ hooks
     def prof_enable(self, on=True):
         self._check(self.lib.k82_prof_enable(self.h, 1 if on else 0))
