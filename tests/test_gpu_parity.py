@@ -569,3 +569,28 @@ def test_epilogue_statistics_match_the_sweep_kernel(engine, monkeypatch):
         assert err <= 1e-4, err
     finally:
         ref_engine.close()
+
+
+@pytest.mark.gpu
+def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
+    """bf16 mode: the ring pipeline of conv_mfma.hip (compile-time tap count, 4 x 1 waves of 32 x 128, one weight slot
+    per tap requested a ci-tile ahead, staging threaded between the MFMAs) sums every output element in the generic
+    loop's order, so an engine built with K82_RING=0 (generic loop everywhere) must reproduce durations and audio
+    exactly on a ragged batch that crosses every tap count (3, 7, 11), both channel widths and all three epilogues."""
+    from tts_amd.engine import Engine
+    id_lists, ref_s = H.make_batch(13, [37, 90, 12, 200, 65])
+    seeds = np.arange(5, dtype=np.uint64) + 70
+    out = []
+    for ring in ("1", "0"):
+        monkeypatch.setenv("K82_RING", ring)
+        eng = Engine(spec.synthetic_state_dicts(0), precision="bf16")
+        try:
+            ids, lens = eng.pack(id_lists)
+            with eng.session():
+                pred, _ = eng.durations(ids, lens, ref_s)
+                audio, off = eng.decode(seeds=seeds)
+            out.append((pred, audio.copy(), off))
+        finally:
+            eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())

@@ -22,6 +22,7 @@
 // xs[2kk+(l>>5)][n+(l&31)+tap*dil], 32 consecutive floats per half-wave = conflict-free.
 // A wave owns a 64(co) x 64(t) tile = 2x2 MFMA tiles = 64 accumulator VGPRs; WM x WN waves per block.
 #include "kernels.h"
+#include <utility>
 
 #ifndef K82_OCC_BF16
 #define K82_OCC_BF16 3              // workgroups per CU (= waves per SIMD) the bf16-mode kernels are built for
@@ -32,6 +33,13 @@
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>) -- every index a constant expression inside f,
+// whatever the optimiser's unroll thresholds (a loop it declines to unroll turns register arrays into scratch memory)
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -142,14 +150,20 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // Linear of the token-rate layers), which takes 32: at 8 MFMAs per tile its K loop is a chain of staging latencies,
 // and twice the channels per barrier halves the chain (1-tap only: with more taps a wider tile would change the
 // order in which an output element's products are summed, and with it the bits).
-template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16>
-__global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
+// TAPS > 0 (bf16 modes): the tap count is a compile-time constant and the kernel runs the RING pipeline (below, "ring
+// pipeline"); TAPS = 0: any tap count / tap mask at run time, two fragment sets one tap ahead.
+// HTN: MFMA tiles per wave along t (default HT: square wave tiles).  The ring pipeline of the bf16 modes runs 4 x 1 waves
+// of 32 (co) x 128 (t): a wave then loads only ITS 32 weight rows per tap -- with 2 x 2 waves of 64 x 64 the two waves
+// that share rows both fetch them, and the L1 -> register return path (TD 88 % busy in the bf16 mode, 33 % MFMA) is what
+// those launches wait for.
+template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT>
+__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
-    constexpr int WT = 32 * HT;                    // rows and columns of a wave's output tile
-    constexpr int BM = WT * WM, BN = WT * WN, KC = KCT, WP = BN + 68, NW = WM * WN;
+    constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
+    constexpr int BM = WT * WM, BN = WTN * WN, KC = KCT, WP = BN + 68, NW = WM * WN;
     static_assert(KC == 16 || (KC == 32 && HT == 1 && !BF16), "32-channel tiles: small-launch fp32 kernel only");
-    static_assert(HT == 2 || (HT == 1 && !BF16), "the 32 x 32 wave tile is an fp32 shape");
+    static_assert(HT == 2 || (HT == 1 && (!BF16 || TAPS > 0)), "one MFMA tile row per wave: the fp32 small-launch shape and the bf16 ring shape");
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
     constexpr int PATCH = 32 * 36 + 64;        // per-wave epilogue patch [32][36] + the wave's 64 bias values
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: Tile stays in SGPRs
     const int wm = wave / WN, wn = wave % WN;
-    const int nw = wn * WT;
+    const int nw = wn * WTN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ntiles = (p.cin_p + KC - 1) / KC, nt16 = p.cin_p / 16;      // staged tiles; 16-channel tiles of the weight images
     const int MT = p.cout_p / BM, NT = (p.Lmax_out + BN - 1) / BN;
@@ -197,12 +211,12 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         return -1;
     };
 
-    floatx16 acc[HT][HT];
+    floatx16 acc[HT][HTN];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < HT; ++i)
 #pragma unroll
-            for (int j = 0; j < HT; ++j)
+            for (int j = 0; j < HTN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         asm volatile("" ::: "memory");
     };
     auto mma_half = [&](const ASet& a, int ni, const BFrag& f) {
+        if constexpr (HT == 2 && HTN == 2)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             if constexpr (SPLIT) {                                     // small terms first
@@ -435,7 +450,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             const int tl = ((T.Lout - 1) >> 2) << 2;
             float4 r4[2][4], a4[2][4];
             auto issue = [&](int idx, float4 (&r)[4], float4 (&a)[4]) {
-                const int mi = idx / HT, ni = idx % HT;
+                const int mi = idx / HTN, ni = idx % HTN;
                 const int tc = min(T.n0 + nw + ni * 32 + c4, tl);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -446,9 +461,9 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
             };
             issue(0, r4[0], a4[0]);
 #pragma unroll
-            for (int idx = 0; idx < HT * HT; ++idx) {
-                const int mi = idx / HT, ni = idx % HT;
-                if (idx + 1 < HT * HT) issue(idx + 1, r4[(idx + 1) & 1], a4[(idx + 1) & 1]);
+            for (int idx = 0; idx < HT * HTN; ++idx) {
+                const int mi = idx / HTN, ni = idx % HTN;
+                if (idx + 1 < HT * HTN) issue(idx + 1, r4[(idx + 1) & 1], a4[(idx + 1) & 1]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
                 const int t = T.n0 + nw + ni * 32 + c4;
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
 #pragma unroll
             for (int mi = 0; mi < HT; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < HT; ++ni) {
+                for (int ni = 0; ni < HTN; ++ni) {
                     const int t = T.n0 + nw + ni * 32 + l31;
                     const int tc = min(t, T.Lout - 1);
                     float rv[16];
@@ -536,6 +551,153 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
     // loads and their use (a conditional definition turns into PHI copies placed right behind the loads,
     // i.e. a wait for them before the MFMAs).  At the very end of a block's walk "next" aliases the current
     // tile, so the one redundant prefetch reads valid addresses and lands in the LDS buffer nobody reads.
+    // ---- ring pipeline (TAPS > 0, bf16 modes) ---------------------------------------------------------------
+    // On the bf16 matrix instruction one tap of a 16-channel tile is 4 MFMAs = 128 pipe cycles per wave (384 in the
+    // split mode) -- a sixteenth of the fp32 tap -- so "one tap ahead" no longer covers anything: the L2 round trip of
+    // the weight fragments (~700 cycles) and each LDS round trip (~150) are exposed on every tap, and that, not the
+    // matrix pipe, LDS bandwidth or instruction count, is where the generic loop spends its time in these modes.
+    // With the tap count known at compile time the loop over the taps of a ci-tile unrolls and
+    //   * the weight fragments live in a RING with one slot per tap: slot j is consumed by tap j of ci-tile i and
+    //     refilled at once with tap j of ci-tile i+1 -- every fragment is requested a whole ci-tile before its use;
+    //   * B fragments are read one tap ahead into a second register set (one exposed LDS round trip per ci-tile);
+    //   * the raw x loads of ci-tile i+2 are issued while ci-tile i computes and are transformed / written to LDS
+    //     during ci-tile i+1: loads return in order, so the wait for a ring slot that was requested a ci-tile ago never
+    //     drains the x loads behind it, and they get a whole ci-tile of latency budget instead of one tap.
+    // The arithmetic per output element (order of ci-tiles, taps, k-halves; the three split terms) is the generic
+    // loop's, so the results are bit-identical to it.
+    if constexpr (TAPS > 0 && BF16) {
+        static_assert(BF16 && KC == 16 && HT * HTN == 4, "the ring pipeline: bf16 modes, four MFMA tiles per wave");
+        constexpr int NQ = (SPLIT ? 2 : 1) * HT;
+        uint4 ring[TAPS][NQ];
+        auto load_ring = [&](int m0, int ci0, int j) {
+            constexpr int FB = SPLIT ? 32 : 16;
+            const char* base = reinterpret_cast<const char*>(p.wb) + ((long)((j * nt16 + ci0 / 16) * 2) * p.cout_p + m0) * FB;
+            const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
+#pragma unroll
+            for (int mi = 0; mi < HT; ++mi) {
+                if constexpr (SPLIT) { ring[j][2 * mi] = wp[64 * mi]; ring[j][2 * mi + 1] = wp[64 * mi + 1]; }
+                else ring[j][mi] = wp[32 * mi];
+            }
+        };
+        // One tap = 4 MFMAs (12 in the split mode).  The staging transform of the NEXT ci-tile is cut into 8 units (a
+        // channel pair x one of the 4 columns a lane carries: affine, Snake / LeakyReLU, validity, bf16 pack, split) and
+        // the units of a tap are issued BETWEEN its MFMAs: a wave issues in order, so VALU work placed after a block of
+        // MFMAs starts only when the last of them has been accepted by the matrix pipe, and two workgroups per CU that
+        // run the same code fall into step (both stage, then both multiply) -- measured on the 128 -> 128, k = 11 launch:
+        // the MFMAs, the staging and the epilogue each cost their full time, nothing overlapped.  In the shadow of its
+        // own MFMAs a wave's VALU work is free.
+        static_assert(NCOL == 1, "the ring pipeline stages one float4 per lane and channel");
+        unsigned hiw[CPW / 2][4], low[CPW / 2][4];
+        auto xunit = [&](const Tile& T, int ci0, int u) {          // u = 4 * pair + column-in-float4, compile-time after unrolling
+            const int pr = u >> 2, e = u & 3;
+            float uu[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = 2 * pr + h;
+                const unsigned lin = (ci0 + chan(cc) < p.cin) ? (unsigned)T.Lin : 0u;
+                const float4 nm = (p.tr == TR_NORM) ? nmr[cc] : nid;
+                const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
+                const float v = e == 0 ? raw[cc][0].x : e == 1 ? raw[cc][0].y : e == 2 ? raw[cc][0].z : raw[cc][0].w;
+                float w = fmaf(v, sc, of);
+                if constexpr (SNAKE) w = snake_fast(w, alr[cc], ialr[cc]);
+                else w = fmaxf(w, w * slope);
+                const unsigned t = (unsigned)(T.tbase + 4 * lane + e);
+                uu[h] = (t < lin) ? w : 0.f;
+            }
+            hiw[pr][e] = pack_bf16(uu[0], uu[1]);
+            if constexpr (SPLIT)
+                low[pr][e] = pack_bf16(uu[0] - __uint_as_float(hiw[pr][e] << 16), uu[1] - __uint_as_float(hiw[pr][e] & 0xffff0000u));
+        };
+        auto xstore = [&](int pr, float* dst) {
+            const int col = 4 * lane;
+            float* d = (col < WP) ? dst + (wave + 4 * pr) * WP + col : patch + 4 * lane;
+            *reinterpret_cast<uint4*>(d) = make_uint4(hiw[pr][0], hiw[pr][1], hiw[pr][2], hiw[pr][3]);
+            if constexpr (SPLIT) {
+                float* d2 = (col < WP) ? dst + (8 + wave + 4 * pr) * WP + col : patch + 4 * lane;
+                *reinterpret_cast<uint4*>(d2) = make_uint4(low[pr][0], low[pr][1], low[pr][2], low[pr][3]);
+            }
+        };
+        // tap J with staging units [U0, U1) of the next ci-tile threaded between its MFMAs
+        auto mma_ring = [&](auto jc, auto u0c, auto u1c, const BFrag (&bf)[HTN], const Tile& T1, int ci1, float* xsn) {
+            constexpr int J = decltype(jc)::value, U0 = decltype(u0c)::value, U1 = decltype(u1c)::value;
+            constexpr int NM = SPLIT ? 12 : 4;
+            static_for<NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int term = SPLIT ? m / 4 : 2, mi = (m & 3) / HTN, ni = (m & 3) % HTN;
+                if constexpr (SPLIT) {     // per accumulator: a_lo b_hi, a_hi b_lo, a_hi b_hi (small terms first), as mma_half
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, ring[J][2 * mi + (term == 0 ? 1 : 0)]);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, term == 1 ? bf[ni].l.v : bf[ni].h.v, acc[mi][ni], 0, 0, 0);
+                } else {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[J][mi]), bf[ni].h.v, acc[mi][ni], 0, 0, 0);
+                }
+                // units spread evenly over the NM gaps of this tap
+                constexpr int lo = U0 + ((U1 - U0) * m + NM - 1) / NM, hi = U0 + ((U1 - U0) * (m + 1) + NM - 1) / NM;
+                static_for<hi - lo>([&](auto uc) {
+                    constexpr int uq = lo + decltype(uc)::value;
+                    xunit(T1, ci1, uq);
+                    if constexpr ((uq & 3) == 3) xstore(uq >> 2, xsn);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        Tile cur, nxt;
+        int q = next_valid(blockIdx.x, cur);
+        if (q < 0) return;
+        // prologue: ci-tile 0 into LDS buffer 0, the raw loads of ci-tile 1 in flight, the ring filled for ci-tile 0
+        load_tile(cur, 0);
+        write_tile(cur, 0, lds);
+        load_tile(cur, KC);                                       // ntiles >= 2 (host-checked): ci-tile 1 is this tile's
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) load_ring(cur.m0, 0, j);
+        __syncthreads();
+        int g = 0;
+        while (true) {
+            const int qn = next_valid(q + G, nxt);
+            const bool have_next = qn >= 0;
+            if (!have_next) nxt = cur;                            // the walk's last prefetches re-read valid addresses
+            const float bias_l = p.bias[min(cur.m0 + lane, p.cout_p - 1)];
+            zero_acc();
+            for (int it = 0; it < ntiles; ++it) {
+                const float* xsb = lds + (g & 1) * (KC * WP);
+                float* xsn = lds + ((g + 1) & 1) * (KC * WP);
+                const bool more1 = it + 1 < ntiles, more2 = it + 2 < ntiles;
+                Tile S1, S2;                                      // by value (a reference to "cur or nxt" sends both to scratch)
+                S1.b = more1 ? cur.b : nxt.b; S1.m0 = more1 ? cur.m0 : nxt.m0; S1.Lin = more1 ? cur.Lin : nxt.Lin; S1.tbase = more1 ? cur.tbase : nxt.tbase;
+                S2.b = more2 ? cur.b : nxt.b; S2.Lin = more2 ? cur.Lin : nxt.Lin; S2.tbase = more2 ? cur.tbase : nxt.tbase;
+                const int ci1 = more1 ? (it + 1) * KC : 0;
+                const int ci2 = more2 ? (it + 2) * KC : (it + 2 - ntiles) * KC;
+                const int off0 = cur.shift;
+                BFrag B[2][HTN];
+#pragma unroll
+                for (int ni = 0; ni < HTN; ++ni) read_b(xsb, off0, ni, B[0][ni]);
+                // staging units per tap: two while they last (k >= 4: taps 0..3), all 8 over the first two taps for k = 3;
+                // the raw loads of ci-tile i+2 go out as soon as the last unit has read the registers they land in
+                constexpr int UPT = TAPS >= 4 ? 2 : 4, ULAST = (8 + UPT - 1) / UPT - 1;
+                static_for<TAPS>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j + 1 < TAPS) {
+#pragma unroll
+                        for (int ni = 0; ni < HTN; ++ni) read_b(xsb, (j + 1) * p.dil + off0, ni, B[(j + 1) & 1][ni]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int u0 = j * UPT < 8 ? j * UPT : 8, u1 = (j + 1) * UPT < 8 ? (j + 1) * UPT : 8;
+                    mma_ring(jc, std::integral_constant<int, u0>{}, std::integral_constant<int, u1>{}, B[j & 1], S1, ci1, xsn);
+                    load_ring(S1.m0, ci1, j);                     // slot j again: tap j of the next ci-tile
+                    if constexpr (j == ULAST) load_tile(S2, ci2);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                ++g;
+            }
+            epilogue(cur, bias_l);
+            if (!have_next) break;
+            cur = nxt;
+            q = qn;
+        }
+        return;
+    }
+
+    if constexpr (TAPS == 0) {
     Tile cur, nxt;
     // Tile walk start.  (An XCD-aware renumbering -- the 64 workgroups of one XCD, b % 8, walking consecutive
     // tiles so halo and shared x tiles stay behind one L2 -- measured 1-6 % SLOWER on the same box than this
@@ -646,15 +808,19 @@ __global__ __launch_bounds__(64 * WM * WN, PREC == 1 ? K82_OCC_BF16 : PREC == 2 
         cur = nxt;
         q = qn;
     }
+    }
 }
 
-template <int WM, int WN, bool SNAKE, int BF16, int HT = 2, int KCT = 16>
+template <int WM, int WN, bool SNAKE, int BF16, int HT = 2, int KCT = 16, int TAPS = 0, int HTN = HT>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     switch (epi) {
-    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
-    default:         hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16, KCT>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p); break;
+    default:
+        if constexpr (SNAKE && TAPS > 0) break;                      // no Snake conv has a scalar epilogue (launch_bf16 never asks)
+        else hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p);
+        break;
     }
 }
 template <int WM, int WN, int HT = 2, int KCT = 16>
@@ -662,7 +828,27 @@ static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) 
     if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT, KCT>(p, epi, grid, s);
     else launch_epi<WM, WN, false, PREC_F32, HT, KCT>(p, epi, grid, s);
 }
+template <int PREC>
+static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
+    // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
+    if (p.dbg == 1 || p.tapmask || p.cin_p < 32) return false;   // dbg = 1: K82_RING=0 (A/B switch of the engine)
+    const bool snake = p.act == ACT_SNAKE;
+    if (snake && epi == EPI_SCALAR) return false;
+    const unsigned grid = (unsigned)(total < 512 ? total : 512);     // two workgroups per CU
+    if (p.taps == 3) {
+        if (snake) launch_epi<4, 1, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
+        else launch_epi<4, 1, false, PREC, 1, 16, 3, 4>(p, epi, grid, s);
+        return true;
+    }
+    if (!snake) return false;
+    if (p.taps == 7) { launch_epi<4, 1, true, PREC, 1, 16, 7, 4>(p, epi, grid, s); return true; }
+    if (p.taps == 11) { launch_epi<4, 1, true, PREC, 1, 16, 11, 4>(p, epi, grid, s); return true; }
+    return false;
+}
 static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {       // 2x2 shape only
+    // plain bf16 only: in the split mode the ring (8 registers per tap) and the doubled B fragments spill, and the build
+    // measured slower than the two-set loop (r02_ab_ring4.log)
+    if (!p.wb_split && launch_ring<PREC_BF16>(p, epi, total, s)) return;
     const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (p.wb_split) {
