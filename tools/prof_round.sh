@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/v17; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG:-r02}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 echo kt done
