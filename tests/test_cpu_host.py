@@ -224,3 +224,52 @@ def test_ordered_gather_pcm16_single_process():
     assert out[0].tolist() == [0, 16383, -32767] and out[1].tolist() == [1, 2]
     with pytest.raises(RuntimeError):
         S.ordered_gather_pcm16({1: np.zeros(3, np.float32)}, 2)
+
+
+# ------------------------------------------------------------------ round-2 known-answer tests (hand-derived)
+def test_abbreviation_splitter_as_shipped():
+    """_split_text_into_sentences (epubviewer_06_latest_1_nov_2025_theme.py:2458-2499) AS SHIPPED: the four
+    typographic-quote replacements are no-ops there (their search strings are plain ASCII quotes in the file), grave /
+    acute accents become apostrophes, a doubled ASCII double quote collapses, abbreviation dots do not end a sentence,
+    and a split needs [.!?] + whitespace + [A-Z0-9'"`([ -- so a sentence opening with a typographic quote is NOT split off."""
+    from tts_amd import text as T
+    f = T.split_sentences_abbrev
+    assert f('He said ""Go."" Then he left. Dr. Smith stayed, e.g. at home. 3 men came! (They left.) ok? yes') == \
+        ['He said "Go." Then he left.', 'Dr. Smith stayed, e.g. at home.', '3 men came!', '(They left.) ok? yes']
+    assert f("It`s here. ´Tis there.") == ["It's here.", "'Tis there."]
+    assert f("One. “Two.” Three.") == ["One. “Two.” Three."]         # typographic quotes pass through
+    assert f("end. lower case follows. Upper") == ["end. lower case follows.", "Upper"]
+    assert f("   ") == [] and f("") == []
+
+
+def test_clean_html_rules_change_the_sentence_list_as_the_reference_does():
+    """generic_clean_html (:5473-5572) before the block walk (:1911-2043): tags outside the allow-list are unwrapped
+    (children kept, adjacent strings merge when the cleaned markup is parsed again), script-like subtrees vanish,
+    question-mark artefacts go, whitespace runs inside text collapse."""
+    from tts_amd import epub
+    html = ('<?xml version="1.0"?><html><head><title>T</title><style>p{}</style></head><body>'
+            '<section><header><h1>Chapter  One</h1></header>'
+            '<p>Wor<font color="red">d</font>s  run\n together. <script>var x = "No. Never.";</script>Next one!</p>'
+            '<p>??</p><p> ? </p><article><p>Inside <em>an</em> article.</p></article></section>'
+            '<nav>Stray nav text. Twice.</nav><!-- a comment. Hidden. --></body></html>')
+    got = [s["text"] for s in epub.sentences_from_html(html)]
+    assert got == ["Chapter One", "Words run together.", "Next one!", "Inside an article.", "Stray nav text.", "Twice."]
+    assert [s["sid"] for s in epub.sentences_from_html(html)] == list(range(6))
+
+
+def test_trim_three_bursts_by_hand():
+    """kokoro_onnx trim == librosa.effects.trim(top_db=60, frame_length=2048, hop_length=512), centred frames: frame f
+    covers samples [512 f - 1024, 512 f + 1024).  Unit-amplitude bursts at [3000, 3100), [8000, 11000), [15000, 15050)
+    in 20000 samples: frame 18 = [8192, 10240) lies inside the long burst, so the reference level is RMS 1; a frame
+    holding even one burst sample has mean square >= 1/2048 = -33 dB > -60 dB.  First such frame: 512 f + 1024 > 3000
+    -> f = 4; last: 512 f - 1024 < 15050 -> f = 31.  Result: y[4 * 512 : 32 * 512] = y[2048:16384]."""
+    from tts_amd import text as T
+    y = np.zeros(20000, np.float32)
+    y[3000:3100] = 1.0
+    y[8000:11000] = 1.0
+    y[15000:15050] = 1.0
+    out, (s, e) = T.trim_audio(y)
+    assert (s, e) == (2048, 16384) and out.size == 16384 - 2048 and np.array_equal(out, y[2048:16384])
+    # 70 dB below the reference is silence: a faint burst does not extend the result
+    y[18000:18010] = 10 ** (-70 / 20) * 14.4          # mean square over a frame: 10 * (a^2) / 2048 -> about -80 dB
+    assert T.trim_audio(y)[1] == (2048, 16384)

@@ -198,3 +198,70 @@ def test_pcm_chunk_sink_and_wav_dir(tmp_path):
     # audio went through PCM_16 WAV files: sample counts survive
     assert total == sum(2400 + 10 * len(t) for t in S[:2])
     assert list(tmp_path.iterdir()) == []                       # played files are removed (speech7.py:373-388)
+
+
+# ------------------------------------------------------------------ the newest harness's policy
+def test_parallel_policy_two_workers_five_ahead_one_sentence_per_task():
+    """epubviewer_06_latest_1_nov_2025_theme.py:406-412,685-756: SYNTHESIS_BUFFER_SIZE = 5 (cur .. cur+4),
+    MAX_PARALLEL_WORKERS = 2, every task is one ``create`` of one sentence; never more than two calls in flight and
+    nothing beyond cur+4 is requested while sentence 0 plays."""
+    sents = [f"Sentence {i}." for i in range(12)]
+    inflight, peak, lock = [0], [0], threading.Lock()
+
+    class Slow(FakeKokoro):
+        def create(self, text, voice, speed=1.0, lang="en-us"):
+            with lock:
+                inflight[0] += 1
+                peak[0] = max(peak[0], inflight[0])
+            try:
+                return super().create(text, voice, speed, lang)
+            finally:
+                with lock:
+                    inflight[0] -= 1
+
+    k = Slow(delay=0.03)
+    sink = ManualSink()
+    e = TTSEngine.parallel(k, sink)
+    assert (e.workers, e.lookahead, e.max_wait, e.keep_behind, e.batch_window) == (2, 4, 5.0, 8, False)
+    e.speak_sentences_list(sents, voice="v")
+    t0 = time.time()
+    while len(k.texts()) < 5 and time.time() - t0 < 5:
+        time.sleep(0.01)
+    time.sleep(0.15)
+    assert sorted(k.texts()) == sorted(sents[:5])                 # the window, and only the window
+    assert all(len(c) == 1 for c in k.calls)                      # one sentence per task, never a batch
+    assert 1 <= peak[0] <= 2
+    e.stop()
+
+
+def test_player_synthesizes_itself_after_max_wait():
+    """:967-993: the player waits at most max_wait (5 s there) for a sentence, then synthesizes it synchronously
+    ("[fallback] Synthesizing idx immediately") and plays what it got."""
+    sents = ["First one.", "Second one."]
+
+    class Stuck(FakeKokoro):
+        def __init__(self):
+            super().__init__()
+            self.release = threading.Event()
+            self.n = 0
+
+        def create(self, text, voice, speed=1.0, lang="en-us"):
+            with self.lock:
+                self.n += 1
+                first = self.n <= 2                               # the two pool workers hang ...
+            if first:
+                self.release.wait(5.0)
+            return super().create(text, voice, speed, lang)       # ... the player's own call goes through
+
+    k = Stuck()
+    sink = NullSink()
+    e = TTSEngine.parallel(k, sink, max_wait=0.2)
+    done = threading.Event()
+    e.speak_sentences_list(sents, voice="v", finished_callback=done.set)
+    t0 = time.time()
+    while not sink.played and time.time() - t0 < 3:
+        time.sleep(0.01)
+    assert sink.played and sink.played[0][0] == 0 and getattr(e, "fallbacks", 0) >= 1
+    k.release.set()
+    assert done.wait(5.0)
+    assert [i for i, _ in sink.played] == [0, 1]

@@ -99,7 +99,16 @@ class PcmChunkSink(NullSink):
 class TTSEngine:
     def __init__(self, kokoro=None, sink: AudioSink = None, dispatch=None, *, lookahead: int = LOOKAHEAD,
                  paused_lookahead: int = PAUSED_LOOKAHEAD, debounce: float = NAV_DEBOUNCE_S, keep_behind: int = 0,
-                 wav_dir: str = None, poll: float = 0.02):
+                 wav_dir: str = None, poll: float = 0.02, workers: int = 1, batch_window: bool = True,
+                 max_wait: float = None):
+        """Defaults = speech7.py's policy (window cur .. cur+3, cur+1 while paused, one synthesis thread) with the
+        window filled by one batched engine call.  ``TTSEngine.parallel(...)`` gives the newest harness's policy
+        (epubviewer_06_latest_1_nov_2025_theme.py:406-412,685-756,967-993): SYNTHESIS_BUFFER_SIZE = 5 sentences
+        (cur .. cur+4), MAX_PARALLEL_WORKERS = 2 threads each synthesizing ONE sentence per task, the player waits at
+        most 5 s for a sentence and then synthesizes it itself, the last CLEANUP_THRESHOLD = 8 sentences stay cached.
+        ``max_wait=None``: wait until the worker delivers or fails (speech7's loop has no time limit while its
+        worker is alive, speech7.py:303-315)."""
+        self.workers, self.batch_window, self.max_wait = max(1, int(workers)), bool(batch_window), max_wait
         self.kokoro = kokoro
         self.sink = sink or NullSink()
         self._dispatch = dispatch or (lambda fn, *a: fn(*a))
@@ -122,6 +131,13 @@ class TTSEngine:
         self._synth_thread = None
         self.synth_log = []                  # [(tuple(indices), seconds)]: one entry per engine call (tests, tuning)
         self._file_seq = 0                   # unique WAV names (the reference's ms timestamp alone can collide)
+
+    @classmethod
+    def parallel(cls, kokoro=None, sink: AudioSink = None, dispatch=None, **kw):
+        """The look-ahead policy of epubviewer_06_latest_1_nov_2025_theme.py (see ``__init__``)."""
+        opts = dict(lookahead=4, paused_lookahead=4, workers=2, batch_window=False, max_wait=5.0, keep_behind=8)
+        opts.update(kw)
+        return cls(kokoro, sink, dispatch, **opts)
 
     # ------------------------------------------------------------------ pieces with reference names
     def split_sentences(self, text):
@@ -209,16 +225,20 @@ class TTSEngine:
                             hold = self._nav_time + self.debounce - now
                             if hold <= 0:
                                 self._nav_time, hold = None, 0.0
-                        missing = [i for i in range(cur, hi + 1) if i not in self._audio and i not in self._failed]
+                        missing = [i for i in range(cur, hi + 1)
+                                   if i not in self._audio and i not in self._failed and i not in self._inflight]
                         if missing and hold <= 0:
                             # the sentence being waited for goes first and alone; the rest of the window in one batch
-                            todo = [cur] if missing[0] == cur else missing
-                            self._inflight = set(todo)
+                            # (or, under the newest harness's policy, one sentence per task as its pool threads do)
+                            todo = [cur] if missing[0] == cur or not self.batch_window else missing
+                            if not self.batch_window:
+                                todo = [missing[0]]
+                            self._inflight |= set(todo)
                             break
                         self._cv.wait(timeout=hold if (missing and hold > 0) else None)
                 res = self._synthesize_many(todo)
                 with self._cv:
-                    self._inflight = set()
+                    self._inflight -= set(todo)
                     if gen != self._gen or self.should_stop:
                         self._discard(res.values())
                         return
@@ -257,8 +277,11 @@ class TTSEngine:
         finished_cb = self._tts_finished_callback        # this list's callback, whatever starts after it
         try:
             total = len(self._tts_sentences)
-            self._synth_thread = threading.Thread(target=self._synthesis_worker, args=(gen,), daemon=True)
-            self._synth_thread.start()
+            self._synth_threads = [threading.Thread(target=self._synthesis_worker, args=(gen,), daemon=True)
+                                   for _ in range(self.workers)]
+            for t in self._synth_threads:
+                t.start()
+            self._synth_thread = self._synth_threads[0]
             self.is_playing = True
             while True:
                 with self._cv:
@@ -269,10 +292,33 @@ class TTSEngine:
                 with self._cv:
                     while self.paused and not self.should_stop and gen == self._gen:
                         self._cv.wait(timeout=0.1)
-                    # wait for this sentence's audio, a navigation, a failure or stop
+                    # wait for this sentence's audio, a navigation, a failure or stop -- at most max_wait seconds
+                    t_wait = time.monotonic()
+                    timed_out = False
                     while (not self.should_stop and gen == self._gen and self._current_play_index == idx
                            and idx not in self._audio and idx not in self._failed and not self.paused):
-                        self._cv.wait(timeout=0.1)
+                        if self.max_wait is not None and time.monotonic() - t_wait >= self.max_wait:
+                            timed_out = True
+                            break
+                        self._cv.wait(timeout=0.05 if self.max_wait is not None else 0.1)
+                    if self.should_stop or gen != self._gen:
+                        break
+                    if self._current_play_index != idx or self.paused:
+                        continue
+                if timed_out:
+                    # epubviewer_06...:982-993 "[fallback] Synthesizing idx immediately": the player synthesizes the
+                    # sentence itself, synchronously, and keeps what it got
+                    print(f"[fallback] Synthesizing {idx} immediately")
+                    a = self.synthesize_sentence(self._tts_sentences[idx], self._tts_voice, self._tts_speed, self._tts_lang)
+                    self.fallbacks = getattr(self, "fallbacks", 0) + 1
+                    with self._cv:
+                        if a is None:
+                            self._failed.add(idx)
+                        elif idx not in self._audio:
+                            self._audio[idx] = a
+                        else:
+                            self._discard([a])
+                with self._cv:
                     if self.should_stop or gen != self._gen:
                         break
                     if self._current_play_index != idx or self.paused:

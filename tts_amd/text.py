@@ -67,7 +67,12 @@ def split_sentences_abbrev(text: str):
     abbreviation dots are protected, then split at [.!?] + whitespace + capital/digit/quote."""
     if not text or not text.strip():
         return []
-    for a, b in (("‘", "'"), ("’", "'"), ("`", "'"), ("´", "'"), ("“", '"'), ("”", '"')):
+    # :2465-2474 AS SHIPPED: the four "smart quote" replacements there have plain ASCII quotes as their search strings
+    # (the typographic characters were lost in the file), so they are no-ops and typographic quotes pass through
+    # untouched -- which also means a sentence that opens with a typographic quote is not a split point for the
+    # look-ahead below.  What does act: grave and acute accents become apostrophes, a doubled ASCII double quote
+    # collapses ('``' can no longer occur after the grave replacement).  Identical results on identical input is the bar.
+    for a, b in (("`", "'"), ("´", "'"), ('""', '"')):
         text = text.replace(a, b)
     mark = "∯"
     protected = re.sub(f"({_ABBREV})\\.", lambda m: m.group(0).replace(".", mark), text, flags=re.IGNORECASE)
