@@ -127,6 +127,14 @@ int k82_synthesize(k82_handle* h, const int64_t* ids, const int32_t* lens, int B
                    int32_t* pred_dur, float* audio, int64_t capacity, int64_t* audio_off,
                    void* stream);
 
+/* Pre-size the handle's workspace for batches of up to B sentences of up to Tmax tokens and `frames` predicted
+ * frames each (1 frame = 600 samples), so that no pass up to that size allocates: SURVEY.md 8b "handle owns weights
+ * + workspace arena sized at create for (Bmax, Tmax, Fmax); no hidden allocations on the hot path".  Without it the
+ * arenas grow on the first pass of each new size (one hipMalloc behind a sync) and never shrink.  Optional; call
+ * after k82_finalize; invalidates the state a preceding k82_durations left.  The reference has no counterpart (its
+ * runtime allocates per call). */
+int k82_reserve(k82_handle* h, int B, int Tmax, int64_t frames);
+
 /* Compute precision of the frame-rate convolutions (decoder + generator; SURVEY.md 8d cfg3 "bf16 decoder").
  *   mode 0 (default): every convolution on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
  *   mode 1: the decoder / generator convolutions round weights and staged activations to bf16 and use

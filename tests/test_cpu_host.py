@@ -273,3 +273,57 @@ def test_trim_three_bursts_by_hand():
     # 70 dB below the reference is silence: a faint burst does not extend the result
     y[18000:18010] = 10 ** (-70 / 20) * 14.4          # mean square over a frame: 10 * (a^2) / 2048 -> about -80 dB
     assert T.trim_audio(y)[1] == (2048, 16384)
+
+
+def test_second_phase_rebucketing_by_predicted_frames():
+    """scheduler.BatchSynthesizer: batches are formed by token count; after phase 1 a batch whose predicted frame
+    counts are too ragged is split by F and each half runs on its own.  A fake engine predicts F = first id of the
+    sentence, so equal-length sentences can be made arbitrarily ragged in frames."""
+    import contextlib
+    from tts_amd.scheduler import BatchSynthesizer
+
+    class FakeEngine:
+        def __init__(self):
+            self.decoded = []
+
+        def session(self):
+            return contextlib.nullcontext(self)
+
+        @staticmethod
+        def pack(id_lists):
+            lens = np.array([len(x) + 2 for x in id_lists], np.int32)
+            ids = np.zeros((len(id_lists), int(lens.max())), np.int64)
+            for b, x in enumerate(id_lists):
+                ids[b, 1:1 + len(x)] = x
+            return ids, lens
+
+        def durations(self, ids, lens, ref_s, speed=None):
+            pred = np.zeros(ids.shape, np.int32)
+            pred[:, 1] = ids[:, 1]                              # F_b = the sentence's first id
+            self._nfr = pred.sum(axis=1).astype(np.int64)
+            self._tag = ids[:, 2].copy()
+            return pred, self._nfr
+
+        def decode(self, seeds=None):
+            self.decoded.append(self._nfr.copy())
+            off = np.concatenate([[0], np.cumsum(600 * self._nfr)])
+            audio = np.concatenate([np.full(600 * int(n), float(t), np.float32) for n, t in zip(self._nfr, self._tag)])
+            return audio, off
+
+    frames = [2, 3, 2, 100, 3, 2, 90, 2]
+    id_lists = [[f, 10 + i, 5, 5] for i, f in enumerate(frames)]   # same token count: one T-bucket, one batch
+    rows = [np.zeros(256, np.float32)] * len(frames)
+    eng = FakeEngine()
+    syn = BatchSynthesizer(eng, frame_pad_limit=1.5)
+    res = syn.synthesize(id_lists, rows)
+    for i, f in enumerate(frames):                                  # every sentence got ITS audio, whatever batch it ran in
+        a, pd = res[i]
+        assert a.size == 600 * f and (a == 10 + i).all() and int(pd.sum()) == f
+    for nfr in eng.decoded:                                         # no decoded batch is more ragged than the limit
+        assert len(nfr) == 1 or int(nfr.max()) * len(nfr) <= 1.5 * int(nfr.sum())
+    assert syn.stats["rebucketed"] >= 1 and syn.stats["frames"] == sum(frames)
+    assert sorted(int(n) for d in eng.decoded for n in d) == sorted(frames)
+    # with the limit off the one T-batch is decoded as it is
+    eng2 = FakeEngine()
+    BatchSynthesizer(eng2, frame_pad_limit=float("inf")).synthesize(id_lists, rows)
+    assert len(eng2.decoded) == 1

@@ -102,3 +102,25 @@ def test_sound_of_sirens_lengths_one_at_a_time(engine, oracle_model):
         assert audios[0].size == 600 * int(pd.sum()) and np.isfinite(audios[0]).all()
         total += audios[0].size / 24000
     print(f"Sound-of-Sirens lengths, {len(pick)} sentences at B=1: {total:.0f} audio-s, durations == oracle")
+
+
+def test_rebucketing_by_predicted_frames_does_not_change_the_audio(engine):
+    """scheduler.BatchSynthesizer re-buckets a ragged batch by predicted F (second phase): with slow and fast speech
+    in one token bucket the frame counts differ 4x, the batch is split, and every sentence's samples are the bits the
+    unsplit batch gives (padding and batch composition are bit-invisible)."""
+    sents = [t for _, t in _book("epub_art_of_war.json.gz")["sentences"]][300:340]
+    ids = _ids_of(sents)
+    pack = spec.synthetic_voice_pack(1)
+    rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
+    speeds = [0.5 if i % 3 == 0 else 2.0 for i in range(len(ids))]
+    seeds = [5000 + i for i in range(len(ids))]
+    plain = BatchSynthesizer(engine, frame_pad_limit=float("inf"))
+    tight = BatchSynthesizer(engine, frame_pad_limit=1.3)
+    a = plain.synthesize(ids, rows, speeds=speeds, seeds=seeds)
+    b = tight.synthesize(ids, rows, speeds=speeds, seeds=seeds)
+    assert tight.stats["rebucketed"] >= 1 and plain.stats["rebucketed"] == 0
+    assert tight.stats["padded_frames"] < plain.stats["padded_frames"]
+    for i in range(len(ids)):
+        assert np.array_equal(a[i][1], b[i][1]) and np.array_equal(a[i][0], b[i][0]), i
+    print(f"padded/real frames: {plain.stats['padded_frames'] / plain.stats['frames']:.2f} -> "
+          f"{tight.stats['padded_frames'] / tight.stats['frames']:.2f} ({tight.stats['rebucketed']} batches re-bucketed)")

@@ -173,3 +173,40 @@ def test_out_of_range_ids_are_an_error_not_a_fault(engine):
     ids2 = np.array([[0, 5, 177, 7, 9, 0]], dtype=np.int64)
     p_host, _ = engine.durations(ids2, lens, ref)
     assert np.array_equal(p_dev, p_host)
+
+
+def test_reserved_workspace_is_not_grown_by_passes_within_the_reservation():
+    """k82_reserve (workspace sized up front, no hidden allocations on the hot path): after reserving for
+    (B, Tmax, frames) every pass within that size runs in the reserved chunks -- the capacity the handle holds does not
+    change -- and gives the bits an unreserved engine gives; a larger pass still works (grows on demand)."""
+    from tts_amd.engine import Engine
+    sds = spec.synthetic_state_dicts(0)
+    id_lists, ref_s = H.make_batch(17, [30, 61, 12, 45])
+    seeds = np.arange(4, dtype=np.uint64)
+    plain = Engine(sds)
+    eng = Engine(sds)
+    try:
+        ids, lens = plain.pack(id_lists)
+        with plain.session():
+            _, nfr = plain.durations(ids, lens, ref_s)
+            want, _ = plain.decode(seeds=seeds)
+        eng.reserve(4, 64, int(nfr.max()) + 50)
+        capT, capF = eng.prof_read("arena_token")[1], eng.prof_read("arena_frame")[1]
+        assert capT > 0 and capF > 0
+        for sub in ([0, 1, 2, 3], [2], [1, 3]):
+            i2, l2 = eng.pack([id_lists[k] for k in sub])
+            with eng.session():
+                eng.durations(i2, l2, ref_s[sub])
+                got, off = eng.decode(seeds=seeds[sub])
+            assert (eng.prof_read("arena_token")[1], eng.prof_read("arena_frame")[1]) == (capT, capF)
+            if sub == [0, 1, 2, 3]:
+                assert np.array_equal(got, want)
+        big, big_ref = H.make_batch(18, [200] * 6)
+        i3, l3 = eng.pack(big)
+        with eng.session():
+            eng.durations(i3, l3, big_ref)
+            a3, _ = eng.decode(seeds=np.arange(6, dtype=np.uint64))
+        assert np.isfinite(a3).all() and eng.prof_read("arena_frame")[1] > capF
+    finally:
+        plain.close()
+        eng.close()

@@ -13,7 +13,7 @@ K82_OK, K82_ENOSPC = 0, -28
 
 EXPORTS = (
     "k82_create", "k82_destroy", "k82_last_error", "k82_set_tensor", "k82_finalize", "k82_durations",
-    "k82_decode", "k82_synthesize", "k82_pcm16", "k82_pcm16_static", "k82_set_precision", "k82_prof_enable", "k82_prof_read", "k82_debug_enable",
+    "k82_decode", "k82_synthesize", "k82_reserve", "k82_pcm16", "k82_pcm16_static", "k82_set_precision", "k82_prof_enable", "k82_prof_read", "k82_debug_enable",
     "k82_debug_info", "k82_debug_copy", "k82_debug_force", "k82_op_conv1d",
 )
 
@@ -60,6 +60,7 @@ def load():
     lib.k82_decode.argtypes = [vp, C.POINTER(K82Noise), vp, i64, vp, vp]
     lib.k82_synthesize.argtypes = [vp, vp, vp, i32, i32, vp, vp, C.POINTER(K82Noise), vp, vp, i64, vp, vp]
     lib.k82_set_precision.argtypes = [vp, C.c_int]
+    lib.k82_reserve.argtypes = [vp, i32, i32, i64]
     lib.k82_pcm16.argtypes = [vp, vp, vp, i64, vp]
     lib.k82_pcm16_static.argtypes = [vp, vp, vp, i64, vp]
     lib.k82_prof_enable.argtypes = [vp, i32]

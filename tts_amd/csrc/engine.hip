@@ -105,6 +105,27 @@ struct Arena {
         return c.p;
     }
     float* f(size_t n) { return (float*)alloc(n * sizeof(float)); }
+    // One chunk of at least `bytes` before the first pass needs it (k82_reserve): later passes up to that size never
+    // reach hipMalloc.  Nothing of a previous pass may be in use.
+    void reserve(size_t bytes) {
+        if (chunks.size() == 1 && chunks[0].cap >= bytes) return;
+        size_t have = 0;
+        for (auto& c : chunks) have = std::max(have, c.cap);
+        if (chunks.size() == 1 && have >= bytes) return;
+        (void)hipDeviceSynchronize();
+        for (auto& c : chunks) (void)hipFree(c.p);
+        chunks.clear();
+        cur = 0; off = 0;
+        Chunk c;
+        c.cap = std::max(bytes, have);
+        if (hipMalloc((void**)&c.p, c.cap) != hipSuccess) {
+            (void)hipGetLastError();
+            throw K82Error(K82_ENOMEM, "hipMalloc of " + std::to_string(c.cap) + " bytes failed (k82_reserve)");
+        }
+        chunks.push_back(c);
+        high = std::max(high, c.cap - c.cap / 8);
+    }
+    size_t capacity() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
     void release() {
         for (auto& c : chunks) (void)hipFree(c.p);
         chunks.clear();
@@ -1301,6 +1322,9 @@ int k82_prof_read(k82_handle* h, const char* name, double* ms, int64_t* launches
         h->prof_drain();
         double m = 0, w = 0; int64_t n = 0; bool found = false;
         if (std::strcmp(name, "lstm_fallbacks") == 0) { n = h->lstm_fallbacks; found = true; }
+        // workspace of the largest pass so far / capacity held now, in bytes (sizing of k82_reserve, tests)
+        if (std::strcmp(name, "arena_token") == 0) { w = (double)std::max(h->aT.high, h->aT.pass_bytes); n = (int64_t)h->aT.capacity(); found = true; }
+        if (std::strcmp(name, "arena_frame") == 0) { w = (double)std::max(h->aF.high, h->aF.pass_bytes); n = (int64_t)h->aF.capacity(); found = true; }
         for (int i = 0; i < NFAM; ++i) {
             const bool match = std::strcmp(name, kFamNames[i]) == 0 || (std::strcmp(name, "conv_mfma") == 0 && i <= FAM_CONV14);
             if (match) { m += h->fam_ms[i]; n += h->fam_n[i]; w += h->fam_work[i]; found = true; }
@@ -1340,6 +1364,22 @@ int k82_debug_force(k82_handle* h, const char* name, const float* data, int64_t 
         t.shape = {rows, cols};
         t.v.assign(data, data + (size_t)rows * cols);
         h->forced[name] = std::move(t);
+    });
+}
+
+int k82_reserve(k82_handle* h, int B, int Tmax, int64_t frames) {
+    return guarded(h, nullptr, [&] {
+        REQUIRE(h->finalized, K82_ESTATE, "k82_finalize has not been called");
+        REQUIRE(B >= 1 && Tmax >= 2 && Tmax <= K82_MAX_TOKENS && frames >= 1 && frames <= 50L * K82_MAX_TOKENS, K82_EINVAL,
+                "k82_reserve: B >= 1, 2 <= Tmax <= 512, 1 <= frames <= 50 * 512");
+        // Measured workspace (k82_prof_read "arena_token" / "arena_frame" over batches from 1 x 8 to 64 x 256 tokens):
+        // the token-rate pass takes 61-84 KB per padded token (B * roundup(Tmax, 32)), the frame-rate pass 0.584-0.599 MB
+        // per padded frame (B * frames) -- tools/arena_probe.py; 5 % and a few MB on top.  A pass that still outgrows the reservation
+        // grows the arena on demand as before.
+        const size_t tok = (size_t)B * (size_t)ru(Tmax, 32), fr = (size_t)B * (size_t)frames;
+        h->have_phase1 = false;
+        h->aT.reserve((size_t)(1.05 * 86.0e3 * (double)tok + 8.0e6));
+        h->aF.reserve((size_t)(1.05 * 0.60e6 * (double)fr + 8.0e6));
     });
 }
 

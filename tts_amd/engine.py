@@ -82,6 +82,13 @@ class Engine:
         self._check(self.lib.k82_set_precision(self.h, mode))
         self.precision = ("fp32", "bf16", "bf16x3")[mode]
 
+    def reserve(self, batch, tokens, frames):
+        """k82_reserve: size the workspace once for batches up to ``batch`` sentences x ``tokens`` tokens x ``frames``
+        predicted frames per sentence, so no later pass of that size allocates."""
+        with self._lock:
+            self._pending = None
+            self._check(self.lib.k82_reserve(self.h, int(batch), int(tokens), int(frames)))
+
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
         if rc != 0:

@@ -77,8 +77,14 @@ def _load_model(model_path, voices_path, device):
 class Kokoro:
     """Drop-in for ``kokoro_onnx.Kokoro`` (pinned 0.4.9, io.github.fastrizwaan.tts.yaml:890-901)."""
 
-    def __init__(self, model_path: str, voices_path: str, device: int = 0, precision: str = "fp32"):
+    def __init__(self, model_path: str, voices_path: str, device: int = 0, precision: str = "fp32",
+                 reserve=(4, 256, 2000)):
+        """``reserve``: (sentences, tokens, frames per sentence) the workspace is sized for up front (k82_reserve), so
+        the first sentences of a read-aloud session do not pay for workspace growth; None skips it.  The default
+        covers the look-ahead window of the readers (4-5 sentences of up to 50 s each) in 4.8 GB of the 288 GB."""
         self.engine, self.config, self.vocab, self.voices = _load_model(model_path, voices_path, device)
+        if reserve:
+            self.engine.reserve(*reserve)
         if precision != "fp32":          # "bf16" / "bf16x3": k82_set_precision (no counterpart in the reference)
             self.engine.set_precision(precision)
         self.synth = BatchSynthesizer(self.engine)

@@ -71,9 +71,18 @@ class BatchSynthesizer:
     """Runs lists of phoneme-id sentences through one Engine in length-bucketed batches and
     returns audio per sentence, in input order."""
 
-    def __init__(self, engine, max_batch: int = 64, max_tokens: int = 64 * 256, frame_budget: int = 160_000):
+    def __init__(self, engine, max_batch: int = 64, max_tokens: int = 64 * 256, frame_budget: int = 160_000,
+                 frame_pad_limit: float = 1.5):
+        """Two-phase execution: batches are formed by token count, phase 1 predicts the
+        durations, and a batch whose PREDICTED frame counts are too ragged -- padded frames B * Fmax above
+        ``frame_pad_limit`` x the real frames, or more real frames than ``frame_budget`` -- is re-bucketed by F: its
+        sentences are ordered by predicted frames and the two halves go through phase 1 + phase 2 on their own (phase 1
+        is ~2 % of a sentence's work, and padding is bit-invisible, so the audio does not change).  The frame-rate
+        workspace is B * Fmax wide, so this bounds memory, not just time."""
         self.engine = engine
         self.max_batch, self.max_tokens, self.frame_budget = max_batch, max_tokens, frame_budget
+        self.frame_pad_limit = frame_pad_limit
+        self.stats = {"batches": 0, "rebucketed": 0, "frames": 0, "padded_frames": 0}
 
     def _run(self, id_lists, ref_rows, speeds, seeds, out, where):
         ids, lens = self.engine.pack(id_lists)
@@ -81,13 +90,20 @@ class BatchSynthesizer:
         # on one engine (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715) interleave whole batches, never halves
         with self.engine.session():
             pred, nfr = self.engine.durations(ids, lens, np.stack(ref_rows), speed=np.asarray(speeds, np.float32))
-            split = int(nfr.sum()) > self.frame_budget and len(id_lists) > 1       # bound the frame-rate workspace
+            real, padded = int(nfr.sum()), int(nfr.max()) * len(id_lists)
+            split = len(id_lists) > 1 and (real > self.frame_budget or padded > self.frame_pad_limit * real)
             if not split:
                 audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
-        if split:
-            h = len(id_lists) // 2
-            self._run(id_lists[:h], ref_rows[:h], speeds[:h], seeds[:h], out, where[:h])
-            self._run(id_lists[h:], ref_rows[h:], speeds[h:], seeds[h:], out, where[h:])
+                self.stats["batches"] += 1
+                self.stats["frames"] += real
+                self.stats["padded_frames"] += padded
+        if split:                                                # second-phase re-bucketing by predicted F
+            self.stats["rebucketed"] += 1
+            order = sorted(range(len(id_lists)), key=lambda k: (int(nfr[k]), k))
+            h = len(order) // 2
+            for part in (order[:h], order[h:]):
+                self._run([id_lists[k] for k in part], [ref_rows[k] for k in part], [speeds[k] for k in part],
+                          [seeds[k] for k in part], out, [where[k] for k in part])
             return
         for k, w in enumerate(where):
             out[w] = (audio[off[k]:off[k + 1]], pred[k, :lens[k]].copy())     # views of the batch buffer: no second copy
