@@ -831,7 +831,7 @@ static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) 
 template <int PREC>
 static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
-    if (p.dbg == 1 || p.tapmask || p.cin_p < 32) return false;   // dbg = 1: K82_RING=0 (A/B switch of the engine)
+    if ((p.dbg & 1) || p.tapmask || p.cin_p < 32) return false;   // dbg = 1: K82_RING=0 (A/B switch of the engine)
     const bool snake = p.act == ACT_SNAKE;
     if (snake && epi == EPI_SCALAR) return false;
     const unsigned grid = (unsigned)(total < 512 ? total : 512);     // two workgroups per CU
