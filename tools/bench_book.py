@@ -26,6 +26,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--max-sentences", type=int, default=0)
 ap.add_argument("--latency-sentences", type=int, default=200)
 ap.add_argument("--max-batch", type=int, default=256)
+ap.add_argument("--frame-pad-limit", type=float, default=None, help="BatchSynthesizer.frame_pad_limit (default: the class default)")
+ap.add_argument("--skip-latency", action="store_true")
 ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32")
 args = ap.parse_args()
 
@@ -42,9 +44,10 @@ pack = spec.synthetic_voice_pack(1)
 rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
 
 eng = Engine(spec.synthetic_state_dicts(0), precision=args.dtype)
-syn = BatchSynthesizer(eng, max_batch=args.max_batch)
+syn = BatchSynthesizer(eng, max_batch=args.max_batch, **({} if args.frame_pad_limit is None else {"frame_pad_limit": args.frame_pad_limit}))
 syn.synthesize(ids[:64], rows[:64])                        # warm-up (arena growth, first launches)
 t0 = time.perf_counter()
+syn.stats = {k: 0 for k in syn.stats}
 res = syn.synthesize(ids, rows)
 dt = time.perf_counter() - t0
 a = audio_seconds([res[i][0] for i in range(len(ids))])
@@ -52,7 +55,10 @@ tok = sum(len(x) + 2 for x in ids)
 print(json.dumps({"config": f"cfg3 (1 GPU, {args.dtype}): The Art of War, every sentence", "sentences": len(ids), "tokens": tok,
                   "mean_tokens": tok / len(ids), "audio_s": a, "wall_s": dt, "audio_s_per_s": a / dt,
                   "phonemes": "surrogate g2p (no phonemizer offline)", "weights": "seeded random",
-                  "includes": "host packing, H2D ids, D2H audio copies per batch"}), flush=True)
+                  "includes": "host packing, H2D ids, D2H audio copies per batch", "scheduler": dict(syn.stats, frame_pad_limit=syn.frame_pad_limit)}), flush=True)
+if args.skip_latency:
+    eng.close()
+    sys.exit(0)
 
 # cfg5: one sentence at a time
 lens = sir["char_lengths"][:args.latency_sentences]

@@ -72,13 +72,17 @@ class BatchSynthesizer:
     returns audio per sentence, in input order."""
 
     def __init__(self, engine, max_batch: int = 64, max_tokens: int = 64 * 256, frame_budget: int = 160_000,
-                 frame_pad_limit: float = 1.5):
+                 frame_pad_limit: float = 3.0):
         """Two-phase execution: batches are formed by token count, phase 1 predicts the
         durations, and a batch whose PREDICTED frame counts are too ragged -- padded frames B * Fmax above
         ``frame_pad_limit`` x the real frames, or more real frames than ``frame_budget`` -- is re-bucketed by F: its
         sentences are ordered by predicted frames and the two halves go through phase 1 + phase 2 on their own (phase 1
         is ~2 % of a sentence's work, and padding is bit-invisible, so the audio does not change).  The frame-rate
-        workspace is B * Fmax wide, so this bounds memory, not just time."""
+        workspace is B * Fmax wide (0.6 MB per padded frame), so this bounds MEMORY; it does not buy time: the conv
+        kernels skip the tiles beyond a sentence's own length, and on The Art of War (padded / real frames = 1.5 when
+        bucketed by tokens alone) a limit of 1.5 measured 5-9 % SLOWER than no limit (17 more, smaller batches and
+        their repeated phase 1) -- hence the loose default, which only catches pathological mixes such as speed 0.5
+        next to speed 2.0 (tests/test_gpu_epub.py)."""
         self.engine = engine
         self.max_batch, self.max_tokens, self.frame_budget = max_batch, max_tokens, frame_budget
         self.frame_pad_limit = frame_pad_limit
