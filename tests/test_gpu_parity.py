@@ -523,7 +523,7 @@ def test_split_and_streaming_lstm_kernels_give_the_same_bits(engine, monkeypatch
     """lstm_split_kernel (four workgroups per recurrence, W_hh in registers, per-step exchange of h through global
     memory) against lstm_kernel (one workgroup streaming W_hh from L2): same chains, same partial-sum tree -- a second
     engine built with K82_LSTM_SPLIT_MAX_B=0 (streaming kernel everywhere) must reproduce durations and audio exactly,
-    for a batch large enough that the split grid (8 workgroups per sentence) runs in more than one round."""
+    on a 40-sentence batch (4 sentences per workgroup: 80 workgroups, one resident round)."""
     from tts_amd.engine import Engine
     lengths = [37, 90, 12, 254] + [40 + (11 * i) % 70 for i in range(36)]
     id_lists, ref_s = H.make_batch(5, lengths)
