@@ -53,3 +53,22 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, fn), encoding="utf-8").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_bench_refuses_a_rank_count_it_cannot_deliver():
+    """bench.py --gpus N must never silently measure fewer GPUs: launched plainly with N = 2 on a
+    machine without GPUs it starts two ranks, both refuse (no GPU for the rank), and the launcher exits non-zero
+    without a JSON line; with a WORLD_SIZE that disagrees with --gpus it names the mismatch."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        return
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout and "needs GPU" in r.stderr and "--gpus 2" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "--gpus 2" in r.stderr
