@@ -157,7 +157,7 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // that share rows both fetch them, and the L1 -> register return path (TD 88 % busy in the bf16 mode, 33 % MFMA) is what
 // those launches wait for.
 template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT>
-__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : 2) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
@@ -566,7 +566,8 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF
     // The arithmetic per output element (order of ci-tiles, taps, k-halves; the three split terms) is the generic
     // loop's, so the results are bit-identical to it.
     if constexpr (TAPS > 0 && BF16) {
-        static_assert(BF16 && KC == 16 && HT * HTN == 4, "the ring pipeline: bf16 modes, four MFMA tiles per wave");
+        static_assert(BF16 && KC == 16 && (HT * HTN == 4 || HT * HTN == 8), "the ring pipeline: bf16 modes, four or eight MFMA tiles per wave");
+        constexpr int NT_ = HT * HTN;                              // MFMA tiles (accumulators) per wave
         constexpr int NQ = (SPLIT ? 2 : 1) * HT;
         uint4 ring[TAPS][NQ];
         auto load_ring = [&](int m0, int ci0, int j) {
@@ -586,10 +587,10 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF
         // run the same code fall into step (both stage, then both multiply) -- measured on the 128 -> 128, k = 11 launch:
         // the MFMAs, the staging and the epilogue each cost their full time, nothing overlapped.  In the shadow of its
         // own MFMAs a wave's VALU work is free.
-        static_assert(NCOL == 1, "the ring pipeline stages one float4 per lane and channel");
-        unsigned hiw[CPW / 2][4], low[CPW / 2][4];
-        auto xunit = [&](const Tile& T, int ci0, int u) {          // u = 4 * pair + column-in-float4, compile-time after unrolling
-            const int pr = u >> 2, e = u & 3;
+        constexpr int NU = (CPW / 2) * NCOL * 4;                   // staging units per ci-tile: (pair, float4 sweep, column)
+        unsigned hiw[CPW / 2][NCOL][4], low[CPW / 2][NCOL][4];
+        auto xunit = [&](const Tile& T, int ci0, int u) {          // u = (pair * NCOL + sweep) * 4 + column-in-float4, a constant after unrolling
+            const int pr = u / (4 * NCOL), k = (u >> 2) % NCOL, e = u & 3;
             float uu[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -597,33 +598,34 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF
                 const unsigned lin = (ci0 + chan(cc) < p.cin) ? (unsigned)T.Lin : 0u;
                 const float4 nm = (p.tr == TR_NORM) ? nmr[cc] : nid;
                 const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
-                const float v = e == 0 ? raw[cc][0].x : e == 1 ? raw[cc][0].y : e == 2 ? raw[cc][0].z : raw[cc][0].w;
+                const float v = e == 0 ? raw[cc][k].x : e == 1 ? raw[cc][k].y : e == 2 ? raw[cc][k].z : raw[cc][k].w;
                 float w = fmaf(v, sc, of);
                 if constexpr (SNAKE) w = snake_fast(w, alr[cc], ialr[cc]);
                 else w = fmaxf(w, w * slope);
-                const unsigned t = (unsigned)(T.tbase + 4 * lane + e);
+                const unsigned t = (unsigned)(T.tbase + 4 * (lane + 64 * k) + e);
                 uu[h] = (t < lin) ? w : 0.f;
             }
-            hiw[pr][e] = pack_bf16(uu[0], uu[1]);
+            hiw[pr][k][e] = pack_bf16(uu[0], uu[1]);
             if constexpr (SPLIT)
-                low[pr][e] = pack_bf16(uu[0] - __uint_as_float(hiw[pr][e] << 16), uu[1] - __uint_as_float(hiw[pr][e] & 0xffff0000u));
+                low[pr][k][e] = pack_bf16(uu[0] - __uint_as_float(hiw[pr][k][e] << 16), uu[1] - __uint_as_float(hiw[pr][k][e] & 0xffff0000u));
         };
-        auto xstore = [&](int pr, float* dst) {
-            const int col = 4 * lane;
+        auto xstore = [&](int pk, float* dst) {                    // pk = pair * NCOL + sweep
+            const int pr = pk / NCOL, k = pk % NCOL;
+            const int col = 4 * (lane + 64 * k);
             float* d = (col < WP) ? dst + (wave + 4 * pr) * WP + col : patch + 4 * lane;
-            *reinterpret_cast<uint4*>(d) = make_uint4(hiw[pr][0], hiw[pr][1], hiw[pr][2], hiw[pr][3]);
+            *reinterpret_cast<uint4*>(d) = make_uint4(hiw[pr][k][0], hiw[pr][k][1], hiw[pr][k][2], hiw[pr][k][3]);
             if constexpr (SPLIT) {
                 float* d2 = (col < WP) ? dst + (8 + wave + 4 * pr) * WP + col : patch + 4 * lane;
-                *reinterpret_cast<uint4*>(d2) = make_uint4(low[pr][0], low[pr][1], low[pr][2], low[pr][3]);
+                *reinterpret_cast<uint4*>(d2) = make_uint4(low[pr][k][0], low[pr][k][1], low[pr][k][2], low[pr][k][3]);
             }
         };
         // tap J with staging units [U0, U1) of the next ci-tile threaded between its MFMAs
         auto mma_ring = [&](auto jc, auto u0c, auto u1c, const BFrag (&bf)[HTN], const Tile& T1, int ci1, float* xsn) {
             constexpr int J = decltype(jc)::value, U0 = decltype(u0c)::value, U1 = decltype(u1c)::value;
-            constexpr int NM = SPLIT ? 12 : 4;
+            constexpr int NM = (SPLIT ? 3 : 1) * NT_;
             static_for<NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                constexpr int term = SPLIT ? m / 4 : 2, mi = (m & 3) / HTN, ni = (m & 3) % HTN;
+                constexpr int term = SPLIT ? m / NT_ : 2, mi = (m % NT_) / HTN, ni = (m % NT_) % HTN;
                 if constexpr (SPLIT) {     // per accumulator: a_lo b_hi, a_hi b_lo, a_hi b_hi (small terms first), as mma_half
                     const bf16x8 a = __builtin_bit_cast(bf16x8, ring[J][2 * mi + (term == 0 ? 1 : 0)]);
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, term == 1 ? bf[ni].l.v : bf[ni].h.v, acc[mi][ni], 0, 0, 0);
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF
                 for (int ni = 0; ni < HTN; ++ni) read_b(xsb, off0, ni, B[0][ni]);
                 // staging units per tap: two while they last (k >= 4: taps 0..3), all 8 over the first two taps for k = 3;
                 // the raw loads of ci-tile i+2 go out as soon as the last unit has read the registers they land in
-                constexpr int UPT = TAPS >= 4 ? 2 : 4, ULAST = (8 + UPT - 1) / UPT - 1;
+                constexpr int UPT0 = (NU + TAPS - 1) / TAPS, UPT = UPT0 < 2 ? 2 : UPT0, ULAST = (NU + UPT - 1) / UPT - 1;
                 static_for<TAPS>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     if constexpr (j + 1 < TAPS) {
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? 2 : PREC == 1 ? K82_OCC_BF
                         for (int ni = 0; ni < HTN; ++ni) read_b(xsb, (j + 1) * p.dil + off0, ni, B[(j + 1) & 1][ni]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    constexpr int u0 = j * UPT < 8 ? j * UPT : 8, u1 = (j + 1) * UPT < 8 ? (j + 1) * UPT : 8;
+                    constexpr int u0 = j * UPT < NU ? j * UPT : NU, u1 = (j + 1) * UPT < NU ? (j + 1) * UPT : NU;
                     mma_ring(jc, std::integral_constant<int, u0>{}, std::integral_constant<int, u1>{}, B[j & 1], S1, ci1, xsn);
                     load_ring(S1.m0, ci1, j);                     // slot j again: tap j of the next ci-tile
                     if constexpr (j == ULAST) load_tile(S2, ci2);
@@ -834,6 +836,8 @@ static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     if ((p.dbg & 1) || p.tapmask || p.cin_p < 32) return false;   // dbg = 1: K82_RING=0 (A/B switch of the engine)
     const bool snake = p.act == ACT_SNAKE;
     if (snake && epi == EPI_SCALAR) return false;
+    // (Measured and not kept: 4 x 1 waves of 32 x 256 at one workgroup per CU -- weight traffic halves again, but with one
+    // wave per SIMD the k = 11 launch went from 0.475 to 0.556 ms; the kernel template still supports HT * HTN = 8.)
     const unsigned grid = (unsigned)(total < 512 ? total : 512);     // two workgroups per CU
     if (p.taps == 3) {
         if (snake) launch_epi<4, 1, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
