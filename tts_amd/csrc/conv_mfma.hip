@@ -22,10 +22,14 @@
 // xs[2kk+(l>>5)][n+(l&31)+tap*dil], 32 consecutive floats per half-wave = conflict-free.
 // A wave owns a 64(co) x 64(t) tile = 2x2 MFMA tiles = 64 accumulator VGPRs; WM x WN waves per block.
 #include "kernels.h"
+#include <cstdlib>
 #include <utility>
 
 #ifndef K82_OCC_BF16
 #define K82_OCC_BF16 3              // workgroups per CU (= waves per SIMD) the bf16-mode kernels are built for
+#endif
+#ifndef K82_OCC_RING
+#define K82_OCC_RING 2
 #endif
 #ifndef K82_SMALL_GRID
 #define K82_SMALL_GRID 512          // fp32 launches whose 128 x 128 tiles would not fill the persistent grid use 64 x 64 tiles
@@ -157,7 +161,7 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // that share rows both fetch them, and the L1 -> register return path (TD 88 % busy in the bf16 mode, 33 % MFMA) is what
 // those launches wait for.
 template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT>
-__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : 2) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
@@ -838,7 +842,7 @@ static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     if (snake && epi == EPI_SCALAR) return false;
     // (Measured and not kept: 4 x 1 waves of 32 x 256 at one workgroup per CU -- weight traffic halves again, but with one
     // wave per SIMD the k = 11 launch went from 0.475 to 0.556 ms; the kernel template still supports HT * HTN = 8.)
-    const unsigned grid = (unsigned)(total < 512 ? total : 512);     // two workgroups per CU
+    const unsigned grid = (unsigned)(total < 256 * K82_OCC_RING ? total : 256 * K82_OCC_RING);     // K82_OCC_RING workgroups per CU
     if (p.taps == 3) {
         if (snake) launch_epi<4, 1, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
         else launch_epi<4, 1, false, PREC, 1, 16, 3, 4>(p, epi, grid, s);
@@ -870,11 +874,12 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
 void launch_conv(const ConvP& p, hipStream_t s) {
     if (p.Lmax_out <= 0 || p.B <= 0) return;
     const int kMaxBlocks = 256 * 2;
+    static const long small_grid = [] { const char* e = getenv("K82_SMALL_GRID"); return e ? atol(e) : (long)K82_SMALL_GRID; }();   // env: tuning only
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
         if (p.wb) launch_bf16(p, epi, total, s);
-        else if (total < K82_SMALL_GRID) {
+        else if (total < small_grid) {
             // too few 128 x 128 tiles to occupy the chip: 64 x 64 tiles (32 x 32 per wave), four times as many
             const long t64 = (long)((p.Lmax_out + 63) / 64) * (p.cout_p / 64) * p.B;
             const unsigned grid = (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks);

@@ -130,6 +130,7 @@ class TTSEngine:
         self._nav_time = None                # monotonic time of the last next/prev
         self._synth_thread = None
         self.synth_log = []                  # [(tuple(indices), seconds)]: one entry per engine call (tests, tuning)
+        self.fallbacks = 0                   # sentences the player had to synthesize itself after max_wait
         self._file_seq = 0                   # unique WAV names (the reference's ms timestamp alone can collide)
 
     @classmethod
@@ -310,7 +311,7 @@ class TTSEngine:
                     # sentence itself, synchronously, and keeps what it got
                     print(f"[fallback] Synthesizing {idx} immediately")
                     a = self.synthesize_sentence(self._tts_sentences[idx], self._tts_voice, self._tts_speed, self._tts_lang)
-                    self.fallbacks = getattr(self, "fallbacks", 0) + 1
+                    self.fallbacks += 1
                     with self._cv:
                         if a is None:
                             self._failed.add(idx)
