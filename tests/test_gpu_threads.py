@@ -210,3 +210,60 @@ def test_reserved_workspace_is_not_grown_by_passes_within_the_reservation():
     finally:
         plain.close()
         eng.close()
+
+
+def _child_synthesize(texts, q):
+    """Producer process (basic.tts_kokoro_2_play_pause_works.py:34-41): builds its OWN Kokoro -- its own HIP context on
+    the same GPU -- and synthesizes while the parent does the same."""
+    import hashlib
+    from tts_amd import Kokoro
+    try:
+        k = Kokoro("synthetic", None)
+        out = []
+        for rep in range(6):
+            for t in texts:
+                a = k.create(t, voice="af_synthetic", trim=False)[0]
+                out.append((t, a.size, hashlib.sha256(a.tobytes()).hexdigest()))
+        fb = k.engine.prof_read("lstm_fallbacks")[1]
+        q.put(("ok", out, fb))
+    except Exception as e:                                          # pragma: no cover
+        q.put(("error", repr(e), 0))
+
+
+def test_parent_and_producer_process_share_one_gpu():
+    """The reference pre-rolls in the parent while a producer PROCESS synthesizes the rest on the same device
+    (basic.tts_kokoro_2_play_pause_works.py:34-41,136-146).  Two processes, two HIP contexts, one GPU: whatever the
+    co-residency of the split BiLSTM kernel turns out to be, both must get the samples a solo run gives (the
+    streaming fallback computes the same bits)."""
+    import hashlib
+    import multiprocessing as mp
+    from tts_amd import Kokoro
+    k = Kokoro("synthetic", None)
+    solo = {t: hashlib.sha256(k.create(t, voice="af_synthetic", trim=False)[0].tobytes()).hexdigest() for t in SENTENCES}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    child = ctx.Process(target=_child_synthesize, args=(SENTENCES, q))
+    child.start()
+    mine = []
+    try:
+        import queue as _q
+        import time
+        t_end, res = time.time() + 120, None
+        while res is None and time.time() < t_end:                  # keep the GPU busy until the producer is done
+            for t in SENTENCES:
+                mine.append((t, hashlib.sha256(k.create(t, voice="af_synthetic", trim=False)[0].tobytes()).hexdigest()))
+            try:
+                res = q.get_nowait()
+            except _q.Empty:
+                pass
+        assert res is not None, "the producer process did not report"
+        status, out, fb_child = res
+    finally:
+        child.join(timeout=60)
+        if child.is_alive():                                        # pragma: no cover
+            child.kill()
+    assert status == "ok", out
+    assert all(h == solo[t] for t, h in mine)
+    assert len(out) == 6 * len(SENTENCES) and all(h == solo[t] for t, _, h in out)
+    assert len(mine) >= len(SENTENCES)
+    print(f"BiLSTM fallbacks while two processes shared the GPU: parent {k.engine.prof_read('lstm_fallbacks')[1]}, child {fb_child}")
