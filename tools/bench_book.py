@@ -28,6 +28,7 @@ ap.add_argument("--latency-sentences", type=int, default=200)
 ap.add_argument("--max-batch", type=int, default=256)
 ap.add_argument("--frame-pad-limit", type=float, default=None, help="BatchSynthesizer.frame_pad_limit (default: the class default)")
 ap.add_argument("--skip-latency", action="store_true")
+ap.add_argument("--prof", action="store_true", help="per-kernel-family GPU time of the cfg3 pass (HIP events; slows it a little)")
 ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32")
 args = ap.parse_args()
 
@@ -48,14 +49,23 @@ syn = BatchSynthesizer(eng, max_batch=args.max_batch, **({} if args.frame_pad_li
 syn.synthesize(ids[:64], rows[:64])                        # warm-up (arena growth, first launches)
 t0 = time.perf_counter()
 syn.stats = {k: 0 for k in syn.stats}
+eng.host_alloc_s = 0.0
+if args.prof:
+    eng.prof_enable(True)
 res = syn.synthesize(ids, rows)
 dt = time.perf_counter() - t0
+fam = {}
+if args.prof:
+    for f in ("conv_mfma_2x2", "conv_mfma_1x4", "lstm", "instnorm", "attention", "istft", "gather", "source", "other"):
+        ms, n, _ = eng.prof_read(f)
+        fam[f] = {"s": ms / 1e3, "launches": n}
+    eng.prof_enable(False)
 a = audio_seconds([res[i][0] for i in range(len(ids))])
 tok = sum(len(x) + 2 for x in ids)
 print(json.dumps({"config": f"cfg3 (1 GPU, {args.dtype}): The Art of War, every sentence", "sentences": len(ids), "tokens": tok,
                   "mean_tokens": tok / len(ids), "audio_s": a, "wall_s": dt, "audio_s_per_s": a / dt,
                   "phonemes": "surrogate g2p (no phonemizer offline)", "weights": "seeded random",
-                  "includes": "host packing, H2D ids, D2H audio copies per batch", "scheduler": dict(syn.stats, frame_pad_limit=syn.frame_pad_limit)}), flush=True)
+                  "includes": "host packing, H2D ids, D2H audio copies per batch", "gpu_seconds_by_family": fam, "scheduler": dict(syn.stats, frame_pad_limit=syn.frame_pad_limit, host_alloc_s=eng.host_alloc_s)}), flush=True)
 if args.skip_latency:
     eng.close()
     sys.exit(0)

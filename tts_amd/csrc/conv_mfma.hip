@@ -879,7 +879,9 @@ void launch_conv(const ConvP& p, hipStream_t s) {
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
         if (p.wb) launch_bf16(p, epi, total, s);
-        else if (total < small_grid) {
+        else if (total < small_grid || p.Lmax_out <= 64) {
+            // (Lmax_out <= 64: token-rate layers of short sentences -- a 128-column tile would be at least half padding;
+            // the book workloads spend a fifth of their time in phase 1 on exactly these.  Same bits either way.)
             // too few 128 x 128 tiles to occupy the chip: 64 x 64 tiles (32 x 32 per wave), four times as many
             const long t64 = (long)((p.Lmax_out + 63) / 64) * (p.cout_p / 64) * p.B;
             const unsigned grid = (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks);

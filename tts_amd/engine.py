@@ -10,6 +10,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
+import time
 
 import numpy as np
 
@@ -58,6 +59,7 @@ class Engine:
         # reference runs two pool threads on one Kokoro object: epubviewer_06_latest_1_nov_2025_theme.py:407,692,715)
         # runs the pair inside ``with engine.session():``.  Re-entrant, so durations()/decode() take it themselves too.
         self._lock = threading.RLock()
+        self.host_alloc_s = 0.0            # seconds spent allocating (page-locked) host buffers for audio
         self._pending = None               # (owner thread id, n_frames) of the durations call a decode may follow
         self.config = config or spec.DEFAULT_CONFIG
         self.device = device
@@ -176,7 +178,9 @@ class Engine:
             ns = _lib.K82Noise(noise=_ptr(nz), seeds=_ptr(K))
             off = np.zeros((B + 1,), dtype=np.int64)
             if out is None:
+                t0 = time.perf_counter()
                 audio = _host_buffer(total)
+                self.host_alloc_s += time.perf_counter() - t0
                 self._check(self.lib.k82_decode(self.h, C.byref(ns), _ptr(audio), total, _ptr(off), _ptr(stream)))
                 return audio, off
             ptr, cap = out

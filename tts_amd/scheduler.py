@@ -8,6 +8,8 @@ final ordered gather of variable-length audio.  No collective touches the forwar
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 from . import spec
@@ -86,18 +88,26 @@ class BatchSynthesizer:
         self.engine = engine
         self.max_batch, self.max_tokens, self.frame_budget = max_batch, max_tokens, frame_budget
         self.frame_pad_limit = frame_pad_limit
-        self.stats = {"batches": 0, "rebucketed": 0, "frames": 0, "padded_frames": 0}
+        self.stats = {"batches": 0, "rebucketed": 0, "frames": 0, "padded_frames": 0,
+                      "s_pack": 0.0, "s_durations": 0.0, "s_decode": 0.0}
 
     def _run(self, id_lists, ref_rows, speeds, seeds, out, where):
+        t0 = time.perf_counter()
         ids, lens = self.engine.pack(id_lists)
+        refs = np.stack(ref_rows)
+        self.stats["s_pack"] += time.perf_counter() - t0
         # the durations -> decode pair shares state inside the handle: one critical section per batch, so two threads
         # on one engine (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715) interleave whole batches, never halves
         with self.engine.session():
-            pred, nfr = self.engine.durations(ids, lens, np.stack(ref_rows), speed=np.asarray(speeds, np.float32))
+            t0 = time.perf_counter()
+            pred, nfr = self.engine.durations(ids, lens, refs, speed=np.asarray(speeds, np.float32))
+            self.stats["s_durations"] += time.perf_counter() - t0
             real, padded = int(nfr.sum()), int(nfr.max()) * len(id_lists)
             split = len(id_lists) > 1 and (real > self.frame_budget or padded > self.frame_pad_limit * real)
             if not split:
+                t0 = time.perf_counter()
                 audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
+                self.stats["s_decode"] += time.perf_counter() - t0
                 self.stats["batches"] += 1
                 self.stats["frames"] += real
                 self.stats["padded_frames"] += padded
