@@ -42,21 +42,21 @@ def _content_seed(ids) -> int:
     return h
 
 
-def _shared_engine(key, state_dicts_fn, config, device):
+def _shared_engine(key, state_dicts_fn, config, device, precision="fp32"):
     """One Engine (one copy of the weights) per (checkpoint, device) per process, built lazily in
     the process that first synthesizes (never at import): child processes that construct their
     own Kokoro (basic.tts_kokoro_2_play_pause_works.py:34-41) get their own HIP context."""
-    k = (key, device, os.getpid())
-    with _engine_lock:
+    k = (key, device, os.getpid(), precision)      # one engine per precision mode: the mode is handle state, and two
+    with _engine_lock:                             # front-door objects must not change each other's arithmetic
         if k not in _engines:
-            _engines[k] = Engine(state_dicts_fn(), config, device)
+            _engines[k] = Engine(state_dicts_fn(), config, device, precision=precision)
         return _engines[k]
 
 
-def _load_model(model_path, voices_path, device):
+def _load_model(model_path, voices_path, device, precision="fp32"):
     if model_path == "synthetic":
         cfg = dict(spec.DEFAULT_CONFIG)
-        eng = _shared_engine("synthetic", lambda: spec.synthetic_state_dicts(0), cfg, device)
+        eng = _shared_engine("synthetic", lambda: spec.synthetic_state_dicts(0), cfg, device, precision)
         voices = {"af_synthetic": spec.synthetic_voice_pack(1)}
         if voices_path and os.path.exists(voices_path):
             voices = W.load_voices(voices_path)
@@ -70,7 +70,7 @@ def _load_model(model_path, voices_path, device):
     vocab = cfg.get("vocab") or dict(spec.DEFAULT_VOCAB)
     if vo is None:
         raise FileNotFoundError(f"no voices file found (voices_path={voices_path!r})")
-    eng = _shared_engine(os.path.abspath(pth), lambda: W.load_pth(pth), cfg, device)
+    eng = _shared_engine(os.path.abspath(pth), lambda: W.load_pth(pth), cfg, device, precision)
     return eng, cfg, vocab, W.load_voices(vo)
 
 
@@ -82,11 +82,9 @@ class Kokoro:
         """``reserve``: (sentences, tokens, frames per sentence) the workspace is sized for up front (k82_reserve), so
         the first sentences of a read-aloud session do not pay for workspace growth; None skips it.  The default
         covers the look-ahead window of the readers (4-5 sentences of up to 50 s each) in 4.8 GB of the 288 GB."""
-        self.engine, self.config, self.vocab, self.voices = _load_model(model_path, voices_path, device)
+        self.engine, self.config, self.vocab, self.voices = _load_model(model_path, voices_path, device, precision)
         if reserve:
             self.engine.reserve(*reserve)
-        if precision != "fp32":          # "bf16" / "bf16x3": k82_set_precision (no counterpart in the reference)
-            self.engine.set_precision(precision)
         self.synth = BatchSynthesizer(self.engine)
 
     @classmethod
