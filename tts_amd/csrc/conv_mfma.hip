@@ -22,6 +22,7 @@
 // xs[2kk+(l>>5)][n+(l&31)+tap*dil], 32 consecutive floats per half-wave = conflict-free.
 // A wave owns a 64(co) x 64(t) tile = 2x2 MFMA tiles = 64 accumulator VGPRs; WM x WN waves per block.
 #include "kernels.h"
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 
@@ -33,6 +34,18 @@
 #endif
 #ifndef K82_SMALL_GRID
 #define K82_SMALL_GRID 512          // fp32 launches whose 128 x 128 tiles would not fill the persistent grid use 64 x 64 tiles
+#endif
+#ifndef K82_BPIPE
+#define K82_BPIPE 1                 // fp32 tap loop: B fragments requested a whole tap ahead (0: the compiler's read-wait-multiply order)
+#endif
+#ifndef K82_EPI_FAST
+#define K82_EPI_FAST 1              // lean epilogue for interior tiles (0: the general path everywhere)
+#endif
+#ifndef K82_OCC_F32
+#define K82_OCC_F32 2               // workgroups per CU of the fp32 kernels
+#endif
+#ifndef K82_TRACE
+#define K82_TRACE 0                 // 1: phase time stamps (tools/trace_conv.py); never in the shipped library
 #endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
@@ -161,7 +174,7 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // that share rows both fetch them, and the L1 -> register return path (TD 88 % busy in the bf16 mode, 33 % MFMA) is what
 // those launches wait for.
 template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT>
-__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : 2) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : K82_OCC_F32) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
@@ -185,6 +198,21 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
     const unsigned tapall = (p.taps >= 32) ? 0xffffffffu : ((1u << p.taps) - 1u);
     float* const patch = lds + 2 * KC * WP + wave * PATCH;
     float* const bsh = patch + 32 * 36;
+#if K82_TRACE
+    // phase time stamps of every wave (tools/trace_conv.py reads them): event = id << 56 | s_memtime
+    constexpr int TRCAP = 1024;
+    unsigned long long* const trb = p.trace + (long)(blockIdx.x * NW + wave) * TRCAP;
+    int trn = 0;
+    auto TR = [&](unsigned long long id) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (lane == 0 && trn < TRCAP) trb[trn] = (id << 56) | (t & 0x00ffffffffffffffull);
+        ++trn;
+    };
+    { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      if (lane == 0) trb[0] = ((unsigned long long)xcc << 32) | hw; trn = 1; }
+#else
+#define TR(id) ((void)0)
+#endif
 
     // ---- persistent tile walk: block g handles output tiles g, g+G, g+2G, ... (m fastest, so the
     // blocks that share an x tile run side by side); everything in Tile is wave-uniform
@@ -408,6 +436,17 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
             }
         }
     };
+    // fp32: B fragments (k-step kk: rows 2 kk + lhi of the tile) as single ds_read_b32 with immediate offsets; the
+    // compiler fences keep the load merger from pairing them into ds_read2_b32 (see mfma_tap)
+    float bpf[2] = {0.f, 0.f};
+    auto read_b32 = [&](const float* xsp, int kk, float (&d)[2]) {
+        d[0] = xsp[2 * kk * WP];
+        asm volatile("" ::: "memory");
+        if constexpr (HT == 2) {
+            d[1] = xsp[2 * kk * WP + 32];
+            asm volatile("" ::: "memory");
+        }
+    };
     // offn: column offset of the next tap of the SAME ci-tile (any valid offset when there is none: the prefetched
     // fragments are then simply not used -- the first step after the barrier reads its own)
     auto mfma_tap = [&](const float* xsb, int off, int offn, const ASet& a) {
@@ -421,6 +460,30 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
             __builtin_amdgcn_sched_barrier(0);
             mma_half(a, 1, f1);
         } else {
+#if K82_BPIPE
+            // All B fragments of the tap are requested up front (k-step 0 came with the previous tap), one ds_read_b32
+            // each off ONE address register: fp32 MFMAs share the SIMD's vector issue with every VALU instruction
+            // (tools/ubench_coissue.hip: time adds, ~5 cycles per instruction, ~20 for one that sits alone between two
+            // MFMAs), LDS instructions do not.  The compiler's own schedule was: read a pair (ds_read2_b32, whose 8-bit
+            // offsets need a v_add_u32 per k-step), wait for it, four MFMAs, next pair.
+            const float* xsp = xsb + lhi * WP + nw + l31 + off;
+            const float* xnp = xsb + lhi * WP + nw + l31 + offn;
+            float bb[KC / 2][2];
+            bb[0][0] = bpf[0]; bb[0][1] = bpf[1];
+#pragma unroll
+            for (int kk = 1; kk < KC / 2; ++kk) read_b32(xsp, kk, bb[kk]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                if (kk == KC / 2 - 2) read_b32(xnp, 0, bpf);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], bb[kk][0], acc[0][0], 0, 0, 0);
+                if constexpr (HT == 2) {
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], bb[kk][1], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], bb[kk][0], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], bb[kk][1], acc[1][1], 0, 0, 0);
+                }
+            }
+#else
             const float* xsp = xsb + lhi * WP + nw + l31 + off;
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
@@ -433,6 +496,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b1, acc[1][1], 0, 0, 0);
                 }
             }
+#endif
         }
     };
 
@@ -446,10 +510,144 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
     // is finished.  Rows are padded to a multiple of 4 floats and nothing downstream reads the padding
     // (every consumer masks by length), so a float4 that starts inside the row is stored whole.
     // bias_l = bias[m0 + lane] was loaded at the start of the tile and reaches the lanes through LDS.
+    // Epilogue VALU budget: on this chip every vector instruction of ANY wave of the SIMD takes its issue cycles away
+    // from the fp32 MFMAs (tools/ubench_coissue.hip: the times add), so the common case -- a wave tile that lies wholly
+    // inside the sentence and the real channels, no GELU -- runs a lean path: no clamps, no validity selects, no
+    // exec-masked stores, row addressing on the scalar unit (per-lane 32-bit byte offsets, host-checked), packed fp32
+    // arithmetic in the fp32 mode (plain in the bf16 modes: v_pk_* does not overlap the bf16 MFMAs, plain VALU does),
+    // the 8-lane statistics sums as v_add_f32_dpp.  Same operations per element in the same order as the general
+    // path: the two give the same bits (tiles of one tensor take different paths).
+    // The wide epilogues read their operands (output / residual / running-mean / statistics pointers, pitches, scales)
+    // from the kernel-argument segment when they start, through an opaque pointer: kept in SGPRs across the main loop
+    // they are spilled to VGPR lanes (the kernel needs ~130 scalar values) and every use costs a v_readlane -- a
+    // vector instruction; an s_load costs none.
+    struct EpiArgs { float* y; const float* res; float* accbuf; float2* stat; long ybs, rbs, abs_, sbs; int ypitch, rpitch, apitch, snt, acc_init, out_act; float out_scale, acc_scale; };
+    auto epi_args = [&]() -> EpiArgs {
+        typedef const ConvP __attribute__((address_space(4))) * KArg;
+        KArg k = (KArg)__builtin_amdgcn_kernarg_segment_ptr();      // ConvP is the kernel's only argument
+        asm volatile("" : "+s"(k));
+        typedef __attribute__((address_space(1))) float GF;
+        typedef __attribute__((address_space(1))) float2 GF2;
+        EpiArgs e;
+        e.y = (float*)(GF*)k->y; e.res = (const float*)(const GF*)k->res; e.accbuf = (float*)(GF*)k->accbuf; e.stat = (float2*)(GF2*)k->stat;
+        e.ybs = k->ybs; e.rbs = k->rbs; e.abs_ = k->abs_; e.sbs = k->sbs;
+        e.ypitch = k->ypitch; e.rpitch = k->rpitch; e.apitch = k->apitch; e.snt = k->snt; e.acc_init = k->acc_init; e.out_act = k->out_act;
+        e.out_scale = k->out_scale; e.acc_scale = k->acc_scale;
+        return e;
+    };
+    auto dpp_sum8x2 = [&](float& s1, float& s2) {
+        // s_nop: a VALU write followed by a DPP read of the same register needs two wait states, and the hazard
+        // recogniser does not look inside an asm block
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "+v"(s1), "+v"(s2));
+    };
+    auto epilogue_fast = [&](const Tile& T, const EpiArgs& E) {
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) floatx4 G4;       // global address space spelled out: the addresses are integers here
+        typedef __attribute__((address_space(1))) floatx2 G2;
+        const int i0 = lane >> 3, c4 = (lane & 7) * 4;
+        const int row = T.m0 + i0, col = T.n0 + nw + c4;
+        // per-lane addresses of the tile's first row; the rows are walked by adding the (scalar) 8-row step.  pin(): an
+        // opaque no-op on the running address -- otherwise all 16 row addresses are formed ahead of the loop, spilled
+        // and fetched back (vector instructions again)
+        auto pin = [](unsigned long& a) { asm volatile("" : "+v"(a)); };
+        const unsigned long y0 = (unsigned long)(E.y + (long)T.b * E.ybs) + (unsigned)(row * E.ypitch + col) * 4u;
+        const unsigned long r0 = EPI >= EPI_RES ? (unsigned long)(E.res + (long)T.b * E.rbs) + (unsigned)(row * E.rpitch + col) * 4u : 0ul;
+        const unsigned long a0 = EPI == EPI_ACC ? (unsigned long)(E.accbuf + (long)T.b * E.abs_) + (unsigned)(row * E.apitch + col) * 4u : 0ul;
+        const unsigned long s0 = (unsigned long)(E.stat + (long)T.b * E.sbs + ((T.n0 + nw) >> 5)) + (unsigned)(row * E.snt) * 8u;
+        const long ystep = (long)E.ypitch * 32, rstep = (long)E.rpitch * 32, astep = (long)E.apitch * 32, sstep = (long)E.snt * 64;   // 8 rows, bytes
+        const bool store_y = EPI != EPI_ACC || E.y;
+        float4 r4[2][4], a4[2][4];
+        auto issue = [&](int idx, float4 (&r)[4], float4 (&a)[4]) {
+            const int mi = idx / HTN, ni = idx % HTN;
+            unsigned long ra = r0 + 4 * mi * rstep, aa = a0 + 4 * mi * astep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (EPI >= EPI_RES) { pin(ra); const floatx4 t = *reinterpret_cast<const G4*>(ra + ni * 128); r[q] = make_float4(t.x, t.y, t.z, t.w); ra += rstep; }
+                if constexpr (EPI == EPI_ACC) { pin(aa); const floatx4 t = *reinterpret_cast<const G4*>(aa + ni * 128); a[q] = make_float4(t.x, t.y, t.z, t.w); aa += astep; }
+            }
+        };
+        issue(0, r4[0], a4[0]);
+#pragma unroll
+        for (int idx = 0; idx < HT * HTN; ++idx) {
+            const int mi = idx / HTN, ni = idx % HTN;
+            if (idx + 1 < HT * HTN) issue(idx + 1, r4[(idx + 1) & 1], a4[(idx + 1) & 1]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
+            unsigned long ya = y0 + 4 * mi * ystep, aa = a0 + 4 * mi * astep, sa = s0 + 4 * mi * sstep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 8 * q;
+                const float4 v4 = *reinterpret_cast<const float4*>(patch + i * 36 + c4);
+                const float bs = bsh[mi * 32 + i];
+                float v[4], av[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!BF16) {
+                    floatx2 x0 = {v4.x, v4.y}, x1 = {v4.z, v4.w};
+                    x0 = x0 + bs; x1 = x1 + bs;
+                    if constexpr (EPI >= EPI_RES) {
+                        const float4 u = r4[idx & 1][q];
+                        x0 = x0 + (floatx2){u.x, u.y}; x1 = x1 + (floatx2){u.z, u.w};
+                    }
+                    x0 = x0 * E.out_scale; x1 = x1 * E.out_scale;
+                    if constexpr (EPI == EPI_ACC) {
+                        const float4 u = a4[idx & 1][q];
+                        floatx2 c0 = {u.x, u.y}, c1 = {u.z, u.w};
+                        if (E.acc_init) { c0 = (floatx2)(0.f); c1 = (floatx2)(0.f); }
+                        c0 = fma2(x0, (floatx2)(E.acc_scale), c0); c1 = fma2(x1, (floatx2)(E.acc_scale), c1);
+                        av[0] = c0.x; av[1] = c0.y; av[2] = c1.x; av[3] = c1.y;
+                    }
+                    v[0] = x0.x; v[1] = x0.y; v[2] = x1.x; v[3] = x1.y;
+                } else {
+                    v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+                    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI >= EPI_RES) { const float4 u = r4[idx & 1][q]; rs[0] = u.x; rs[1] = u.y; rs[2] = u.z; rs[3] = u.w; }
+                    if constexpr (EPI == EPI_ACC) {
+                        const float4 u = a4[idx & 1][q];
+                        av[0] = E.acc_init ? 0.f : u.x; av[1] = E.acc_init ? 0.f : u.y;
+                        av[2] = E.acc_init ? 0.f : u.z; av[3] = E.acc_init ? 0.f : u.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = v[e] + bs;
+                        if constexpr (EPI >= EPI_RES) u += rs[e];
+                        u *= E.out_scale;
+                        v[e] = u;
+                        av[e] = fmaf(u, E.acc_scale, av[e]);
+                    }
+                }
+                if (E.stat) {                                   // wave-uniform
+                    float s1 = 0.f + v[0], s2 = v[0] * v[0];
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+                    dpp_sum8x2(s1, s2);
+                    int c4o = c4;
+                    asm volatile("" : "+v"(c4o));               // (compared afresh: the hoisted lane mask would be another spilled SGPR pair)
+                    pin(sa);
+                    if (c4o == 0) *reinterpret_cast<G2*>(sa + ni * 8) = (floatx2){s1, s2};
+                    sa += sstep;
+                }
+                if (store_y) { pin(ya); *reinterpret_cast<G4*>(ya + ni * 128) = (floatx4){v[0], v[1], v[2], v[3]}; ya += ystep; }
+                if constexpr (EPI == EPI_ACC) { pin(aa); *reinterpret_cast<G4*>(aa + ni * 128) = (floatx4){av[0], av[1], av[2], av[3]}; aa += astep; }
+            }
+        }
+    };
     auto epilogue = [&](const Tile& T, float bias_l) {
-        const long yb = (long)T.b * p.ybs, rb = (long)T.b * p.rbs, ab = (long)T.b * p.abs_;
         bsh[lane] = bias_l;
         if constexpr (EPI != EPI_SCALAR) {
+            const EpiArgs E = epi_args();
+            const long yb = (long)T.b * E.ybs, rb = (long)T.b * E.rbs, ab = (long)T.b * E.abs_;
+#if K82_EPI_FAST
+            if (E.out_act != OACT_GELU_NEW && T.n0 + nw + WTN <= T.Lout && T.m0 + WT <= p.cout) { epilogue_fast(T, E); return; }
+#endif
             const int i0 = lane >> 3, c4 = (lane & 7) * 4;
             const int tl = ((T.Lout - 1) >> 2) << 2;
             float4 r4[2][4], a4[2][4];
@@ -459,8 +657,8 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int mc = min(T.m0 + mi * 32 + i0 + 8 * q, p.cout - 1);
-                    if constexpr (EPI >= EPI_RES) r[q] = *reinterpret_cast<const float4*>(p.res + rb + (long)mc * p.rpitch + tc);
-                    if constexpr (EPI == EPI_ACC) a[q] = *reinterpret_cast<const float4*>(p.accbuf + ab + (long)mc * p.apitch + tc);
+                    if constexpr (EPI >= EPI_RES) r[q] = *reinterpret_cast<const float4*>(E.res + rb + (long)mc * E.rpitch + tc);
+                    if constexpr (EPI == EPI_ACC) a[q] = *reinterpret_cast<const float4*>(E.accbuf + ab + (long)mc * E.apitch + tc);
                 }
             };
             issue(0, r4[0], a4[0]);
@@ -482,18 +680,19 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     if constexpr (EPI >= EPI_RES) { const float4 u = r4[idx & 1][q]; rs[0] = u.x; rs[1] = u.y; rs[2] = u.z; rs[3] = u.w; }
                     if constexpr (EPI == EPI_ACC) {
                         const float4 u = a4[idx & 1][q];
-                        av[0] = p.acc_init ? 0.f : u.x; av[1] = p.acc_init ? 0.f : u.y;
-                        av[2] = p.acc_init ? 0.f : u.z; av[3] = p.acc_init ? 0.f : u.w;
+                        av[0] = E.acc_init ? 0.f : u.x; av[1] = E.acc_init ? 0.f : u.y;
+                        av[2] = E.acc_init ? 0.f : u.z; av[3] = E.acc_init ? 0.f : u.w;
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float u = v[e] + bs;
-                        if (p.out_act == OACT_GELU_NEW) u = gelu_new(u);
-                        u = (u + rs[e]) * p.out_scale;
+                        if (E.out_act == OACT_GELU_NEW) u = gelu_new(u);
+                        if constexpr (EPI >= EPI_RES) u += rs[e];
+                        u *= E.out_scale;
                         v[e] = u;
-                        av[e] = av[e] + u * p.acc_scale;
+                        av[e] = av[e] + u * E.acc_scale;
                     }
-                    if (p.stat) {                               // wave-uniform: instance-norm partials of this row span
+                    if (E.stat) {                               // wave-uniform: instance-norm partials of this row span
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -504,17 +703,18 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                         s1 = sum8(s1);
                         s2 = sum8(s2);
                         if (c4 == 0 && m < p.cout && t < T.Lout)
-                            p.stat[(long)T.b * p.sbs + (long)m * p.snt + (t >> 5)] = make_float2(s1, s2);
+                            E.stat[(long)T.b * E.sbs + (long)m * E.snt + (t >> 5)] = make_float2(s1, s2);
                     }
                     if (m < p.cout && t < T.Lout) {             // stores only under the lane-dependent condition
-                        if (EPI != EPI_ACC || p.y)
-                            *reinterpret_cast<float4*>(p.y + yb + (long)m * p.ypitch + t) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (EPI != EPI_ACC || E.y)
+                            *reinterpret_cast<float4*>(E.y + yb + (long)m * E.ypitch + t) = make_float4(v[0], v[1], v[2], v[3]);
                         if constexpr (EPI == EPI_ACC)
-                            *reinterpret_cast<float4*>(p.accbuf + ab + (long)m * p.apitch + t) = make_float4(av[0], av[1], av[2], av[3]);
+                            *reinterpret_cast<float4*>(E.accbuf + ab + (long)m * E.apitch + t) = make_float4(av[0], av[1], av[2], av[3]);
                     }
                 }
             }
         } else {
+            const long yb = (long)T.b * p.ybs, rb = (long)T.b * p.rbs;
             const int upmask = (1 << p.up_cout_shift) - 1;
             const float* resp = p.res ? p.res + rb : p.bias;      // always a readable address: no branch per load
             const int rpitch = p.res ? p.rpitch : 0;
@@ -721,6 +921,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
         if (!have_next) nxt = cur;
         const float bias_l = p.bias[min(cur.m0 + lane, p.cout_p - 1)];   // bias is padded to cout_p; lands during the main loop
         zero_acc();
+        TR(1);
         int tap = cur.tap0;
         auto next_tap = [&](int t) -> int {
             const unsigned mm = (t >= 31) ? 0u : (cur.mask >> (t + 1));
@@ -746,7 +947,11 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
             // in-order vmcnt, for the loads issued just before them).
             ASet& X = a0;
             ASet& Y = a1;
+            TR(2);
             if constexpr (BF16) read_b(xsb, tap * p.dil + cur.shift, 0, bpre);
+#if K82_BPIPE
+            else read_b32(xsb + lhi * WP + nw + l31 + tap * p.dil + cur.shift, 0, bpf);
+#endif
             {
                 {   // first active tap: stage + compute
                     const bool single = cur.nact == 1;
@@ -756,7 +961,9 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     __builtin_amdgcn_sched_barrier(0);     // loads are issued BEFORE the MFMAs (the scheduler sinks them otherwise)
                     mfma_tap(xsb, tap * p.dil + cur.shift, ntap * p.dil + cur.shift, X);    // (single: ntap is a tap of this conv too)
                     __builtin_amdgcn_sched_barrier(0);     // ... and waited for only after the MFMAs are in the pipe
+                    TR(3);
                     write_tile(S, sci0, xsn);
+                    TR(4);
                     tap = ntap;
                 }
                 int j = 1;
@@ -806,10 +1013,13 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
             }
             // raw barrier: LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e. wait here for the
             // weight fragments just requested for the next ci-tile.
+            TR(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ++g;
         }
+        TR(6);
         epilogue(cur, bias_l);
+        TR(7);
         if (!have_next) break;
         cur = nxt;
         q = qn;
@@ -871,9 +1081,31 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
 // Persistent launch: at most CUS x BLOCKS_PER_CU workgroups walk the output tiles.
 // Host-checked operand contract (engine.hip run_conv): bias != nullptr and padded to cout_p; accbuf implies
 // res and a wide epilogue; y != nullptr unless accbuf; all pitches % 4 == 0 and bases 16-byte aligned.
+#if K82_TRACE
+static void launch_conv_inner(const ConvP& p, hipStream_t s);
+void launch_conv(const ConvP& p0, hipStream_t s) {
+    // trace build: every launch stamps into one device buffer; the last launch's stamps are written to $K82_TRACE_FILE
+    static unsigned long long* buf = nullptr;
+    const size_t bytes = (size_t)768 * 4 * 1024 * 8;
+    if (!buf && hipMalloc(&buf, bytes) != hipSuccess) abort();
+    hipMemsetAsync(buf, 0, bytes, s);
+    ConvP p = p0;
+    p.trace = buf;
+    launch_conv_inner(p, s);
+    if (const char* f = getenv("K82_TRACE_FILE")) {
+        hipStreamSynchronize(s);
+        void* h = malloc(bytes);
+        hipMemcpy(h, buf, bytes, hipMemcpyDeviceToHost);
+        if (FILE* fp = fopen(f, "wb")) { fwrite(h, 1, bytes, fp); fclose(fp); }
+        free(h);
+    }
+}
+static void launch_conv_inner(const ConvP& p, hipStream_t s) {
+#else
 void launch_conv(const ConvP& p, hipStream_t s) {
+#endif
     if (p.Lmax_out <= 0 || p.B <= 0) return;
-    const int kMaxBlocks = 256 * 2;
+    const int kMaxBlocks = 256 * K82_OCC_F32;
     static const long small_grid = [] { const char* e = getenv("K82_SMALL_GRID"); return e ? atol(e) : (long)K82_SMALL_GRID; }();   // env: tuning only
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {

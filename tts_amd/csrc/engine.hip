@@ -666,6 +666,10 @@ struct k82_handle {
         REQUIRE(p.act != ACT_LEAKY || (p.slope >= 0.f && p.slope <= 1.f), K82_EINVAL, "LeakyReLU slope must be in [0, 1]");
         REQUIRE(p.tr != TR_NORM || p.norm, K82_EINVAL, "norm transform needs statistics");
         REQUIRE(!p.stat || (p.y && !p.up_s && !p.res_shift && p.snt * 32 >= p.Lmax_out), K82_EINVAL, "statistics partials need a stored, plain-layout output");
+        // the lean epilogue addresses a sentence's rows with 32-bit byte offsets
+        const long kMaxElems = 1L << 30;
+        REQUIRE((long)p.cout_p * p.ypitch < kMaxElems && (long)p.cout_p * p.rpitch < kMaxElems && (long)p.cout_p * p.apitch < kMaxElems &&
+                (!p.stat || (long)p.cout_p * p.snt < (kMaxElems >> 1)), K82_EINVAL, "conv output of one sentence exceeds 4 GB");
     }
     void run_conv(const ConvP& p, const int* host_base) {
         check_conv(p);
