@@ -20,14 +20,16 @@ from tts_amd.engine import Engine  # noqa: E402
 
 args = [int(a) for a in sys.argv[1:]]
 cin, cout, L, B, taps, dil, act = (args + [128, 128, 92161, 8, 3, 1, 2][len(args):])[:7]
-path = os.environ.setdefault("K82_TRACE_FILE", "/tmp/k82_trace.bin")
+path = os.environ.pop("K82_TRACE_FILE", "/tmp/k82_trace.bin")
 eng = Engine(spec.synthetic_state_dicts(0), precision="fp32")
 rng = np.random.default_rng(0)
 x = rng.standard_normal((B, cin, L)).astype(np.float32)
 w = (rng.standard_normal((cout, cin, taps)) / np.sqrt(cin * taps)).astype(np.float32)
 b = rng.standard_normal(cout).astype(np.float32)
 alpha = (1 + 0.5 * rng.random(cin)).astype(np.float32)
-_, ms = eng.op_conv1d(x, w, b, dil=dil, act=act, slope=0.2, alpha=alpha if act == 2 else None, iters=3)
+_, ms = eng.op_conv1d(x, w, b, dil=dil, act=act, slope=0.2, alpha=alpha if act == 2 else None, iters=5)   # stamps on, no dump
+os.environ["K82_TRACE_FILE"] = path
+eng.op_conv1d(x, w, b, dil=dil, act=act, slope=0.2, alpha=alpha if act == 2 else None, iters=1)
 print(f"cin {cin} cout {cout} L {L} B {B} k {taps} d {dil} act {act}: {ms:.3f} ms per launch (trace build)")
 
 CAP = 1024
@@ -42,12 +44,13 @@ for row in buf:
     ts = (row[1:n] & MASK).astype(np.int64)
     waves.append((int(row[0]), ids, ts))
 print(f"{len(waves)} waves traced, {sum(len(w[1]) for w in waves)} stamps")
-t0 = min(w[2][0] for w in waves)
-t1 = max(w[2][-1] for w in waves)
+firsts = np.array([w[2][0] for w in waves]); lasts = np.array([w[2][-1] for w in waves])
+t0 = int(np.median(firsts)); t1 = int(np.median(lasts))
 tick_us = (t1 - t0) / (ms * 1e3)
-print(f"span {t1 - t0} ticks ~ {tick_us:.1f} ticks/us (kernel {ms * 1e3:.0f} us)")
+print(f"median first stamp -> median last stamp: {t1 - t0} ticks ~ {tick_us:.1f} ticks/us (kernel {ms * 1e3:.0f} us); "
+      f"first stamps spread {int(firsts.max() - firsts.min())}, last stamps spread {int(lasts.max() - lasts.min())}")
 
-names = {(1, 2): "tile start -> first ci-tile", (2, 3): "ci-tile: loads + first tap issued", (3, 4): "ci-tile: staging (wait x, transform, LDS write)",
+names = {(3, 8): "ci-tile: wait for the x tile", (8, 4): "ci-tile: transform + LDS write", (1, 2): "tile start -> first ci-tile", (2, 3): "ci-tile: loads + first tap issued", (3, 4): "ci-tile: staging (wait x, transform, LDS write)",
          (4, 5): "ci-tile: remaining taps issued", (5, 2): "ci-tile: barrier (wait for the workgroup)", (5, 6): "last barrier-less gap",
          (6, 7): "epilogue", (7, 1): "tile switch (next tile, bias, zero acc)", (4, 2): "(one-tap) -> next ci-tile"}
 acc = {}
@@ -67,7 +70,7 @@ for k, (s, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
 def idle_intervals(ids, ts):
     out = []
     for a, s, e in zip(ids[:-1], ts[:-1], ts[1:]):
-        if a in (3, 5, 6, 7, 1):          # staging, barrier, epilogue, tile switch
+        if a in (3, 8, 5, 6, 7, 1):       # staging, barrier, epilogue, tile switch
             out.append((s, e))
     return out
 

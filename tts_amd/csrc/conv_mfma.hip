@@ -295,6 +295,11 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
     // compare against the row length (0 for padded channels).
     auto write_tile = [&](const Tile& T, int ci0, float* dst) {
         float out[CPW][NCOL][4];
+        // (Measured and not kept: touching the per-channel parameters with an opaque asm here so that "scale = rstd * (1 +
+        // gamma)" is computed behind the tap's MFMAs -- instruction selection places it right behind the loads, in front
+        // of the tap, with an s_waitcnt for their L2 round trip.  The wait is real (tools/trace_conv.py: the first tap of
+        // a ci-tile takes 1.2-2.1 us longer than the others) but the partner wave covers it: pinned 2044, unpinned 2063
+        // audio-s/s on one box.)
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const unsigned lin = (ci0 + chan(cc) < p.cin) ? (unsigned)T.Lin : 0u;
@@ -962,6 +967,10 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     mfma_tap(xsb, tap * p.dil + cur.shift, ntap * p.dil + cur.shift, X);    // (single: ntap is a tap of this conv too)
                     __builtin_amdgcn_sched_barrier(0);     // ... and waited for only after the MFMAs are in the pipe
                     TR(3);
+#if K82_TRACE
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the x tile has arrived (4 weight loads behind it)
+                    TR(8);
+#endif
                     write_tile(S, sci0, xsn);
                     TR(4);
                     tap = ntap;
