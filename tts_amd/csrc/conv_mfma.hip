@@ -47,6 +47,9 @@
 #ifndef K82_TRACE
 #define K82_TRACE 0                 // 1: phase time stamps (tools/trace_conv.py); never in the shipped library
 #endif
+#ifndef K82_STAGE_FAST
+#define K82_STAGE_FAST 0            // 1: staging without validity selects for interior tiles -- 40 fewer vector instructions per ci-tile, measured 1.5 % SLOWER (profiles/r02_ab_stage_fast.txt)
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -293,7 +296,8 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
     // offset = beta - mean * scale: within 2 ulp of the reference's (x - mean) * rstd * (1 + gamma) + beta),
     // LeakyReLU is max(u, slope * u) (slope in [0, 1], checked on the host), validity is one unsigned
     // compare against the row length (0 for padded channels).
-    auto write_tile = [&](const Tile& T, int ci0, float* dst) {
+    auto write_tile_impl = [&](auto interior_c, const Tile& T, int ci0, float* dst) {
+        constexpr bool INTERIOR = decltype(interior_c)::value;     // every staged column and channel is real: no validity selects
         float out[CPW][NCOL][4];
         // (Measured and not kept: touching the per-channel parameters with an opaque asm here so that "scale = rstd * (1 +
         // gamma)" is computed behind the tap's MFMAs -- instruction selection places it right behind the loads, in front
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                         floatx2 u = fma2(v2[h], (floatx2)(sc), (floatx2)(of));
                         if constexpr (SNAKE) u = snake2(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
                         else { const floatx2 w = u * slope; u.x = fmaxf(u.x, w.x); u.y = fmaxf(u.y, w.y); }
-                        out[cc][k][2 * h] = (t + 2 * h < lin) ? u.x : 0.f;      // t < 0 wraps to a huge unsigned: also invalid
-                        out[cc][k][2 * h + 1] = (t + 2 * h + 1 < lin) ? u.y : 0.f;
+                        out[cc][k][2 * h] = (INTERIOR || t + 2 * h < lin) ? u.x : 0.f;      // t < 0 wraps to a huge unsigned: also invalid
+                        out[cc][k][2 * h + 1] = (INTERIOR || t + 2 * h + 1 < lin) ? u.y : 0.f;
                     }
                 } else {
                     const float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                         float u = fmaf(v[e], sc, of);
                         if constexpr (SNAKE) u = snake_fast(u, alr[cc], ialr[cc]);
                         else u = fmaxf(u, u * slope);
-                        out[cc][k][e] = (t + e < lin) ? u : 0.f;
+                        out[cc][k][e] = (INTERIOR || t + e < lin) ? u : 0.f;
                     }
                 }
             }
@@ -364,6 +368,16 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     }
                 }
         }
+    };
+    // Interior tiles (every column the taps read lies inside the sentence, every channel of the ci-tile is real) skip the
+    // validity selects: 2 of the ~13 vector instructions per element pair, and every vector instruction of the staging
+    // step is issue time the SIMD's fp32 MFMAs do not get (tools/ubench_coissue.hip).  Same values either way.
+    auto write_tile = [&](const Tile& T, int ci0, float* dst) {
+#if K82_STAGE_FAST
+        if (T.tbase >= 0 && T.tbase + WP <= T.Lin && ci0 + KC <= p.cin) write_tile_impl(std::true_type{}, T, ci0, dst);
+        else
+#endif
+            write_tile_impl(std::false_type{}, T, ci0, dst);
     };
 
     // Two sets of A fragments: the one being consumed and the one being loaded.  fp32: f[kk][mi] scalars;
