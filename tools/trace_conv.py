@@ -21,7 +21,7 @@ from tts_amd.engine import Engine  # noqa: E402
 args = [int(a) for a in sys.argv[1:]]
 cin, cout, L, B, taps, dil, act = (args + [128, 128, 92161, 8, 3, 1, 2][len(args):])[:7]
 path = os.environ.pop("K82_TRACE_FILE", "/tmp/k82_trace.bin")
-eng = Engine(spec.synthetic_state_dicts(0), precision="fp32")
+eng = Engine(spec.synthetic_state_dicts(0), precision=os.environ.get("K82_PRECISION", "fp32"))
 rng = np.random.default_rng(0)
 x = rng.standard_normal((B, cin, L)).astype(np.float32)
 w = (rng.standard_normal((cout, cin, taps)) / np.sqrt(cin * taps)).astype(np.float32)
@@ -51,7 +51,7 @@ print(f"median first stamp -> median last stamp: {t1 - t0} ticks ~ {tick_us:.1f}
       f"first stamps spread {int(firsts.max() - firsts.min())}, last stamps spread {int(lasts.max() - lasts.min())}")
 
 names = {(3, 8): "ci-tile: wait for the x tile", (8, 4): "ci-tile: transform + LDS write", (1, 2): "tile start -> first ci-tile", (2, 3): "ci-tile: loads + first tap issued", (3, 4): "ci-tile: staging (wait x, transform, LDS write)",
-         (4, 5): "ci-tile: remaining taps issued", (5, 2): "ci-tile: barrier (wait for the workgroup)", (5, 6): "last barrier-less gap",
+         (4, 5): "ci-tile: remaining taps issued", (2, 5): "ci-tile: all taps (+ threaded staging, ring pipeline)", (5, 2): "ci-tile: barrier (wait for the workgroup)", (5, 6): "last barrier-less gap",
          (6, 7): "epilogue", (7, 1): "tile switch (next tile, bias, zero acc)", (4, 2): "(one-tap) -> next ci-tile"}
 acc = {}
 for hw, ids, ts in waves:

@@ -121,10 +121,12 @@ __device__ __forceinline__ float sum8(float v) {
 // bf16 mode only: sin through the hardware v_sin_f32 (argument in revolutions, ~1e-6 absolute error for the
 // |alpha v| < 256 * 2 pi this model produces): 4 instructions instead of 14 -- in bf16 mode the staging VALU, not
 // the matrix pipe, is what the Snake convolutions wait for.
-__device__ __forceinline__ float snake_fast(float v, float al, float ial) {
-    const float sn = __builtin_amdgcn_sinf(al * v * 0.15915494309189535f);
+// alrev = alpha / (2 pi), formed once per channel and ci-tile (one multiply per element less)
+__device__ __forceinline__ float snake_fast(float v, float alrev, float ial) {
+    const float sn = __builtin_amdgcn_sinf(alrev * v);
     return fmaf(ial, sn * sn, v);
 }
+constexpr float kInvTwoPi = 0.15915494309189535f;
 
 //
 // PREC = 2, "bf16x3": fp32-grade products from the bf16 matrix pipe.  Every operand is split into two bf16
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float u = fmaf(v[e], sc, of);
-                        if constexpr (SNAKE) u = snake_fast(u, alr[cc], ialr[cc]);
+                        if constexpr (SNAKE) u = snake_fast(u, alr[cc] * kInvTwoPi, ialr[cc]);
                         else u = fmaxf(u, u * slope);
                         out[cc][k][e] = (INTERIOR || t + e < lin) ? u : 0.f;
                     }
@@ -812,25 +814,44 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
         // own MFMAs a wave's VALU work is free.
         constexpr int NU = (CPW / 2) * NCOL * 4;                   // staging units per ci-tile: (pair, float4 sweep, column)
         unsigned hiw[CPW / 2][NCOL][4], low[CPW / 2][NCOL][4];
+        // Per-channel parameters of the ci-tile being staged, formed by the first unit of each channel pair and pinned
+        // (left to itself the compiler rebuilds scale / offset / selects in every unit: 80 of the 216 vector instructions
+        // of a k = 11 ci-tile, and the per-wave instruction stream is what bounds this kernel -- tools/trace_conv.py).
+        // A padded channel gets scale = offset = 0, which stages exact zeros for finite inputs without a per-element
+        // select; the column validity is applied once to the packed dword.
+        float scx[CPW], ofx[CPW], arx[CPW];
         auto xunit = [&](const Tile& T, int ci0, int u) {          // u = (pair * NCOL + sweep) * 4 + column-in-float4, a constant after unrolling
             const int pr = u / (4 * NCOL), k = (u >> 2) % NCOL, e = u & 3;
+            if (u % (4 * NCOL) == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cc = 2 * pr + h;
+                    const bool real = ci0 + chan(cc) < p.cin;
+                    const float4 nm = (p.tr == TR_NORM) ? nmr[cc] : nid;
+                    const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
+                    scx[cc] = real ? sc : 0.f;
+                    ofx[cc] = real ? of : 0.f;
+                    if constexpr (SNAKE) { arx[cc] = alr[cc] * kInvTwoPi; asm volatile("" : "+v"(arx[cc])); }
+                    asm volatile("" : "+v"(scx[cc]), "+v"(ofx[cc]));
+                }
+            }
             float uu[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int cc = 2 * pr + h;
-                const unsigned lin = (ci0 + chan(cc) < p.cin) ? (unsigned)T.Lin : 0u;
-                const float4 nm = (p.tr == TR_NORM) ? nmr[cc] : nid;
-                const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
                 const float v = e == 0 ? raw[cc][k].x : e == 1 ? raw[cc][k].y : e == 2 ? raw[cc][k].z : raw[cc][k].w;
-                float w = fmaf(v, sc, of);
-                if constexpr (SNAKE) w = snake_fast(w, alr[cc], ialr[cc]);
+                float w = fmaf(v, scx[cc], ofx[cc]);
+                if constexpr (SNAKE) w = snake_fast(w, arx[cc], ialr[cc]);
                 else w = fmaxf(w, w * slope);
-                const unsigned t = (unsigned)(T.tbase + 4 * (lane + 64 * k) + e);
-                uu[h] = (t < lin) ? w : 0.f;
+                uu[h] = w;
             }
-            hiw[pr][k][e] = pack_bf16(uu[0], uu[1]);
-            if constexpr (SPLIT)
-                low[pr][k][e] = pack_bf16(uu[0] - __uint_as_float(hiw[pr][k][e] << 16), uu[1] - __uint_as_float(hiw[pr][k][e] & 0xffff0000u));
+            const bool valid = (unsigned)(T.tbase + 4 * (lane + 64 * k) + e) < (unsigned)T.Lin;      // t < 0 wraps: invalid too
+            const unsigned hi = pack_bf16(uu[0], uu[1]);
+            hiw[pr][k][e] = valid ? hi : 0u;
+            if constexpr (SPLIT) {
+                const unsigned lo = pack_bf16(uu[0] - __uint_as_float(hi << 16), uu[1] - __uint_as_float(hi & 0xffff0000u));
+                low[pr][k][e] = valid ? lo : 0u;
+            }
         };
         auto xstore = [&](int pk, float* dst) {                    // pk = pair * NCOL + sweep
             const int pr = pk / NCOL, k = pk % NCOL;
@@ -882,7 +903,9 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
             if (!have_next) nxt = cur;                            // the walk's last prefetches re-read valid addresses
             const float bias_l = p.bias[min(cur.m0 + lane, p.cout_p - 1)];
             zero_acc();
+            TR(1);
             for (int it = 0; it < ntiles; ++it) {
+                TR(2);
                 const float* xsb = lds + (g & 1) * (KC * WP);
                 float* xsn = lds + ((g + 1) & 1) * (KC * WP);
                 const bool more1 = it + 1 < ntiles, more2 = it + 2 < ntiles;
@@ -911,10 +934,13 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     if constexpr (j == ULAST) load_tile(S2, ci2);
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                TR(5);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 ++g;
             }
+            TR(6);
             epilogue(cur, bias_l);
+            TR(7);
             if (!have_next) break;
             cur = nxt;
             q = qn;
