@@ -50,6 +50,9 @@
 #ifndef K82_STAGE_FAST
 #define K82_STAGE_FAST 0            // 1: staging without validity selects for interior tiles -- 40 fewer vector instructions per ci-tile, measured 1.5 % SLOWER (profiles/r02_ab_stage_fast.txt)
 #endif
+#ifndef K82_RING_SMEM
+#define K82_RING_SMEM 1             // ring pipeline: per-channel staging parameters through the scalar cache (0: vector loads, A/B only)
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
     // raw global loads of one ci-tile (no transform yet): wave w takes channels w, w+NW, ...
     // All loads are UNCONDITIONAL with clamped (always in-bounds) coordinates; validity is applied
     // later with selects.
-    auto load_tile = [&](const Tile& T, int ci0) {
+    auto load_tile = [&](const Tile& T, int ci0, bool params = true) {      // params: a constant at every call site
         const float* xb = p.x + (long)T.b * p.xbs;
         const int tlast = ((T.Lin - 1) >> 2) << 2;          // last aligned float4 that starts inside the row
 #pragma unroll
@@ -285,8 +288,10 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                 const int t = min(max(T.tbase + 4 * (lane + 64 * k), 0), tlast);
                 raw[cc][k] = *reinterpret_cast<const float4*>(xr + t);
             }
-            nmr[cc] = normp[(long)T.b * nstride + min(ci, nclamp)];
-            if constexpr (SNAKE) { alr[cc] = p.alpha[ci]; ialr[cc] = p.inv_alpha[ci]; }
+            if (params) {
+                nmr[cc] = normp[(long)T.b * nstride + min(ci, nclamp)];
+                if constexpr (SNAKE) { alr[cc] = p.alpha[ci]; ialr[cc] = p.inv_alpha[ci]; }
+            }
         }
     };
     // transform (AdaIN affine, activation) and write to the LDS buffer; zero padding stays zero.
@@ -819,10 +824,52 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
         // of a k = 11 ci-tile, and the per-wave instruction stream is what bounds this kernel -- tools/trace_conv.py).
         // A padded channel gets scale = offset = 0, which stages exact zeros for finite inputs without a per-element
         // select; the column validity is applied once to the packed dword.
-        float scx[CPW], ofx[CPW], arx[CPW];
+        float scx[CPW], ofx[CPW], arx[CPW], ialx[CPW];
         auto xunit = [&](const Tile& T, int ci0, int u) {          // u = (pair * NCOL + sweep) * 4 + column-in-float4, a constant after unrolling
             const int pr = u / (4 * NCOL), k = (u >> 2) % NCOL, e = u & 3;
             if (u % (4 * NCOL) == 0) {
+#if K82_RING_SMEM
+                // The pair's parameters come through the SCALAR cache (one s_load_dwordx8 + two s_load_dwordx2 per pair):
+                // as wave-uniform vector loads they were 6 of the 21 KB a wave pulls through the L1 return path per
+                // ci-tile, and that path (TD 87 % busy, profiles/r02_pmc_conv_bf16_ring_k11.txt) is what this kernel
+                // waits for.  Read-only data, written by earlier kernels; the ring is only launched for cin % 16 == 0,
+                // so both channels of a pair are real and adjacent.
+                typedef unsigned uintx8 __attribute__((ext_vector_type(8)));
+                typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+                const int cp = ci0 + 2 * wave + 8 * pr;             // == ci0 + chan(2 * pr)
+                float sc2[2], of2[2];
+                if (p.tr == TR_NORM) {
+                    const float4* pn = p.norm + (long)T.b * p.nstride + cp;
+                    uintx8 n8;
+                    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(n8) : "s"(pn) : "memory");
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float mean = __uint_as_float(n8[4 * h]), rstd = __uint_as_float(n8[4 * h + 1]), g1 = __uint_as_float(n8[4 * h + 2]), beta = __uint_as_float(n8[4 * h + 3]);
+                        sc2[h] = rstd * g1;
+                        of2[h] = fmaf(-mean, sc2[h], beta);
+                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { sc2[h] = nid.y * nid.z; of2[h] = fmaf(-nid.x, sc2[h], nid.w); }
+                }
+                if constexpr (SNAKE) {
+                    const float* pa = p.alpha + cp;
+                    const float* pi = p.inv_alpha + cp;
+                    uintx2 a2, i2;
+                    asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a2), "=&s"(i2) : "s"(pa), "s"(pi) : "memory");
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        arx[2 * pr + h] = __uint_as_float(a2[h]) * kInvTwoPi;
+                        ialx[2 * pr + h] = __uint_as_float(i2[h]);
+                        asm volatile("" : "+v"(arx[2 * pr + h]), "+v"(ialx[2 * pr + h]));
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    scx[2 * pr + h] = sc2[h]; ofx[2 * pr + h] = of2[h];
+                    asm volatile("" : "+v"(scx[2 * pr + h]), "+v"(ofx[2 * pr + h]));
+                }
+#else
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int cc = 2 * pr + h;
@@ -831,9 +878,10 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     const float sc = nm.y * nm.z, of = fmaf(-nm.x, sc, nm.w);
                     scx[cc] = real ? sc : 0.f;
                     ofx[cc] = real ? of : 0.f;
-                    if constexpr (SNAKE) { arx[cc] = alr[cc] * kInvTwoPi; asm volatile("" : "+v"(arx[cc])); }
+                    if constexpr (SNAKE) { arx[cc] = alr[cc] * kInvTwoPi; ialx[cc] = ialr[cc]; asm volatile("" : "+v"(arx[cc])); }
                     asm volatile("" : "+v"(scx[cc]), "+v"(ofx[cc]));
                 }
+#endif
             }
             float uu[2];
 #pragma unroll
@@ -841,7 +889,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                 const int cc = 2 * pr + h;
                 const float v = e == 0 ? raw[cc][k].x : e == 1 ? raw[cc][k].y : e == 2 ? raw[cc][k].z : raw[cc][k].w;
                 float w = fmaf(v, scx[cc], ofx[cc]);
-                if constexpr (SNAKE) w = snake_fast(w, arx[cc], ialr[cc]);
+                if constexpr (SNAKE) w = snake_fast(w, arx[cc], ialx[cc]);
                 else w = fmaxf(w, w * slope);
                 uu[h] = w;
             }
@@ -892,7 +940,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
         // prologue: ci-tile 0 into LDS buffer 0, the raw loads of ci-tile 1 in flight, the ring filled for ci-tile 0
         load_tile(cur, 0);
         write_tile(cur, 0, lds);
-        load_tile(cur, KC);                                       // ntiles >= 2 (host-checked): ci-tile 1 is this tile's
+        load_tile(cur, KC, !K82_RING_SMEM);                       // ntiles >= 2 (host-checked): ci-tile 1 is this tile's
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) load_ring(cur.m0, 0, j);
         __syncthreads();
@@ -931,7 +979,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                     constexpr int u0 = j * UPT < NU ? j * UPT : NU, u1 = (j + 1) * UPT < NU ? (j + 1) * UPT : NU;
                     mma_ring(jc, std::integral_constant<int, u0>{}, std::integral_constant<int, u1>{}, B[j & 1], S1, ci1, xsn);
                     load_ring(S1.m0, ci1, j);                     // slot j again: tap j of the next ci-tile
-                    if constexpr (j == ULAST) load_tile(S2, ci2);
+                    if constexpr (j == ULAST) load_tile(S2, ci2, !K82_RING_SMEM);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 TR(5);
@@ -1096,7 +1144,7 @@ static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) 
 template <int PREC>
 static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
-    if ((p.dbg & 1) || p.tapmask || p.cin_p < 32) return false;   // dbg = 1: K82_RING=0 (A/B switch of the engine)
+    if ((p.dbg & 1) || p.tapmask || p.cin_p < 32 || p.cin % 16 != 0) return false;   // (cin % 16: the staging reads its parameters per channel PAIR)   // dbg = 1: K82_RING=0 (A/B switch of the engine)
     const bool snake = p.act == ACT_SNAKE;
     if (snake && epi == EPI_SCALAR) return false;
     // (Measured and not kept: 4 x 1 waves of 32 x 256 at one workgroup per CU -- weight traffic halves again, but with one
