@@ -53,6 +53,9 @@
 #ifndef K82_RING_SMEM
 #define K82_RING_SMEM 1             // ring pipeline: per-channel staging parameters through the scalar cache (0: vector loads, A/B only)
 #endif
+#ifndef K82_RING_WN
+#define K82_RING_WN 2               // ring pipeline: 2 = large launches run 4 x 2 waves on 128 x 256 tiles (1: always 4 x 1)
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -182,7 +185,7 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // that share rows both fetch them, and the L1 -> register return path (TD 88 % busy in the bf16 mode, 33 % MFMA) is what
 // those launches wait for.
 template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT>
-__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : K82_OCC_F32) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 || WM * WN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : K82_OCC_F32) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
 
     // channel (within the ci-tile) that staging slot cc of this wave carries: fp32 w, w+NW, ...; bf16 modes the
     // channel pairs (2w, 2w+1) and (8+2w, 8+2w+1), i.e. rows w and 4+w of the packed tile
-    auto chan = [&](int cc) -> int { return BF16 ? 2 * wave + (cc & 1) + 8 * (cc >> 1) : wave + cc * NW; };
-    static_assert(!BF16 || (NW == 4 && CPW == 4), "the packed bf16 staging assumes 4 waves x 4 channels");
+    auto chan = [&](int cc) -> int { return BF16 ? 2 * (wave + NW * (cc >> 1)) + (cc & 1) : wave + cc * NW; };
+    static_assert(!BF16 || (NW * CPW == 16 && CPW % 2 == 0), "the packed bf16 staging: every wave carries whole channel pairs of a 16-channel tile");
     float4 raw[CPW][NCOL], nmr[CPW];
     float alr[CPW], ialr[CPW];
     // Per-channel transform parameters always come from a readable address (the padded bias vector stands
@@ -367,10 +370,10 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                         if constexpr (SPLIT)
                             lo[e] = pack_bf16(u0 - __uint_as_float(hi[e] << 16), u1 - __uint_as_float(hi[e] & 0xffff0000u));
                     }
-                    float* d = (col < WP) ? dst + (wave + 4 * pr) * WP + col : patch + 4 * lane;
+                    float* d = (col < WP) ? dst + (wave + NW * pr) * WP + col : patch + 4 * lane;
                     *reinterpret_cast<uint4*>(d) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
                     if constexpr (SPLIT) {
-                        float* d2 = (col < WP) ? dst + (8 + wave + 4 * pr) * WP + col : patch + 4 * lane;
+                        float* d2 = (col < WP) ? dst + (8 + wave + NW * pr) * WP + col : patch + 4 * lane;
                         *reinterpret_cast<uint4*>(d2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
                     }
                 }
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
                 // so both channels of a pair are real and adjacent.
                 typedef unsigned uintx8 __attribute__((ext_vector_type(8)));
                 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-                const int cp = ci0 + 2 * wave + 8 * pr;             // == ci0 + chan(2 * pr)
+                const int cp = ci0 + 2 * (wave + NW * pr);          // == ci0 + chan(2 * pr)
                 float sc2[2], of2[2];
                 if (p.tr == TR_NORM) {
                     const float4* pn = p.norm + (long)T.b * p.nstride + cp;
@@ -904,10 +907,10 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
         auto xstore = [&](int pk, float* dst) {                    // pk = pair * NCOL + sweep
             const int pr = pk / NCOL, k = pk % NCOL;
             const int col = 4 * (lane + 64 * k);
-            float* d = (col < WP) ? dst + (wave + 4 * pr) * WP + col : patch + 4 * lane;
+            float* d = (col < WP) ? dst + (wave + NW * pr) * WP + col : patch + 4 * lane;
             *reinterpret_cast<uint4*>(d) = make_uint4(hiw[pr][k][0], hiw[pr][k][1], hiw[pr][k][2], hiw[pr][k][3]);
             if constexpr (SPLIT) {
-                float* d2 = (col < WP) ? dst + (8 + wave + 4 * pr) * WP + col : patch + 4 * lane;
+                float* d2 = (col < WP) ? dst + (8 + wave + NW * pr) * WP + col : patch + 4 * lane;
                 *reinterpret_cast<uint4*>(d2) = make_uint4(low[pr][k][0], low[pr][k][1], low[pr][k][2], low[pr][k][3]);
             }
         };
@@ -1127,12 +1130,12 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OC
 template <int WM, int WN, bool SNAKE, int BF16, int HT = 2, int KCT = 16, int TAPS = 0, int HTN = HT>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     switch (epi) {
-    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p); break;
-    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p); break;
+    case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
+    case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
+    case EPI_ACC:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_ACC, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
     default:
         if constexpr (SNAKE && TAPS > 0) break;                      // no Snake conv has a scalar epilogue (launch_bf16 never asks)
-        else hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
         break;
     }
 }
@@ -1149,6 +1152,24 @@ static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     if (snake && epi == EPI_SCALAR) return false;
     // (Measured and not kept: 4 x 1 waves of 32 x 256 at one workgroup per CU -- weight traffic halves again, but with one
     // wave per SIMD the k = 11 launch went from 0.475 to 0.556 ms; the kernel template still supports HT * HTN = 8.)
+    // Large launches: 4 x 2 waves, 128 x 256 tiles, ONE workgroup per CU -- the two waves that own the same 32 weight rows
+    // run in step (one barrier per ci-tile), so the second one's fragment loads hit the L1 lines the first one just
+    // missed on, and the x halo is shared by twice the columns: +2.9 % on configs[1] in bf16 (6972 -> 7173 audio-s/s,
+    // profiles/r02_ab_ring_wn2_bf16.txt); single launches of the shapes lose 3-7 % at k >= 7 and the book workloads do
+    // not move, so launches with fewer than two rounds of 256-column tiles keep 4 x 1 waves and two workgroups per CU.
+    const long t256 = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 128) * p.B;
+    if (K82_RING_WN == 2 && t256 >= 2 * 256) {
+        const unsigned grid = 256;
+        if (p.taps == 3) {
+            if (snake) launch_epi<4, 2, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
+            else launch_epi<4, 2, false, PREC, 1, 16, 3, 4>(p, epi, grid, s);
+            return true;
+        }
+        if (!snake) return false;
+        if (p.taps == 7) { launch_epi<4, 2, true, PREC, 1, 16, 7, 4>(p, epi, grid, s); return true; }
+        if (p.taps == 11) { launch_epi<4, 2, true, PREC, 1, 16, 11, 4>(p, epi, grid, s); return true; }
+        return false;
+    }
     const unsigned grid = (unsigned)(total < 256 * K82_OCC_RING ? total : 256 * K82_OCC_RING);     // K82_OCC_RING workgroups per CU
     if (p.taps == 3) {
         if (snake) launch_epi<4, 1, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
