@@ -578,19 +578,22 @@ def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
     loop's order, so an engine built with K82_RING=0 (generic loop everywhere) must reproduce durations and audio
     exactly on a ragged batch that crosses every tap count (3, 7, 11), both channel widths and all three epilogues."""
     from tts_amd.engine import Engine
-    id_lists, ref_s = H.make_batch(13, [37, 90, 12, 200, 65])
-    seeds = np.arange(5, dtype=np.uint64) + 70
-    out = []
-    for ring in ("1", "0"):
-        monkeypatch.setenv("K82_RING", ring)
-        eng = Engine(spec.synthetic_state_dicts(0), precision="bf16")
-        try:
-            ids, lens = eng.pack(id_lists)
-            with eng.session():
-                pred, _ = eng.durations(ids, lens, ref_s)
-                audio, off = eng.decode(seeds=seeds)
-            out.append((pred, audio.copy(), off))
-        finally:
-            eng.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
-    assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())
+    # the long batch runs the generator stages on the 4 x 2-wave ring (128 x 256 tiles: launches with at least two rounds
+    # of them), the short one keeps every launch on the 4 x 1-wave ring
+    for lengths in ([37, 90, 12, 200, 65], [9, 14]):
+        id_lists, ref_s = H.make_batch(13, lengths)
+        seeds = np.arange(len(lengths), dtype=np.uint64) + 70
+        out = []
+        for ring in ("1", "0"):
+            monkeypatch.setenv("K82_RING", ring)
+            eng = Engine(spec.synthetic_state_dicts(0), precision="bf16")
+            try:
+                ids, lens = eng.pack(id_lists)
+                with eng.session():
+                    pred, _ = eng.durations(ids, lens, ref_s)
+                    audio, off = eng.decode(seeds=seeds)
+                out.append((pred, audio.copy(), off))
+            finally:
+                eng.close()
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+        assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())
