@@ -56,6 +56,9 @@
 #ifndef K82_RING_WN
 #define K82_RING_WN 2               // ring pipeline: 2 = large launches run 4 x 2 waves on 128 x 256 tiles (1: always 4 x 1)
 #endif
+#ifndef K82_SPLIT_14
+#define K82_SPLIT_14 1              // bf16x3: 4 x 1 waves of 32 x 128 in the two-set loop (0: 2 x 2 waves of 64 x 64)
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 || WM * WN >
     constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
     constexpr int BM = WT * WM, BN = WTN * WN, KC = KCT, WP = BN + 68, NW = WM * WN;
     static_assert(KC == 16 || (KC == 32 && HT == 1 && !BF16), "32-channel tiles: small-launch fp32 kernel only");
-    static_assert(HT == 2 || (HT == 1 && (!BF16 || TAPS > 0)), "one MFMA tile row per wave: the fp32 small-launch shape and the bf16 ring shape");
+    static_assert(HT == 2 || (HT == 1 && (!BF16 || HTN == 4)), "one MFMA tile row per wave: the fp32 small-launch shape and the 32 x 128 bf16 shapes");
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
     constexpr int PATCH = 32 * 36 + 64;        // per-wave epilogue patch [32][36] + the wave's 64 bias values
@@ -407,8 +410,8 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 || WM * WN >
             const char* base = reinterpret_cast<const char*>(p.wb) +
                                ((long)((tap * nt16 + ci0 / 16) * 2) * p.cout_p + m0) * FB;
             const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
-            if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; a.q[2] = wp[64]; a.q[3] = wp[65]; }
-            else { a.q[0] = wp[0]; a.q[1] = wp[32]; }
+            if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; if constexpr (HT == 2) { a.q[2] = wp[64]; a.q[3] = wp[65]; } }
+            else { a.q[0] = wp[0]; if constexpr (HT == 2) a.q[1] = wp[32]; }
         } else if constexpr (WM == 2 && WN == 2) {              // (both wave-tile sizes)
             // fragment image: the lane's 8 k-step values of a row are 32 contiguous bytes -- 4 x 16-byte loads per
             // tap instead of 16 dword loads
@@ -465,6 +468,16 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 || WM * WN >
             }
         }
     };
+    auto mma_tile14 = [&](const ASet& a, int ni, const BFrag& f) {       // HT = 1, HTN = 4 (32 x 128 wave tile), generic loop
+        if constexpr (SPLIT) {                                         // same three terms, same order as mma_half
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, a.q[0]), al = __builtin_bit_cast(bf16x8, a.q[1]);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f.h.v, acc[0][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.l.v, acc[0][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.h.v, acc[0][ni], 0, 0, 0);
+        } else {
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.q[0]), f.h.v, acc[0][ni], 0, 0, 0);
+        }
+    };
     // fp32: B fragments (k-step kk: rows 2 kk + lhi of the tile) as single ds_read_b32 with immediate offsets; the
     // compiler fences keep the load merger from pairing them into ds_read2_b32 (see mfma_tap)
     float bpf[2] = {0.f, 0.f};
@@ -479,7 +492,26 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 || WM * WN >
     // offn: column offset of the next tap of the SAME ci-tile (any valid offset when there is none: the prefetched
     // fragments are then simply not used -- the first step after the barrier reads its own)
     auto mfma_tap = [&](const float* xsb, int off, int offn, const ASet& a) {
-        if constexpr (BF16) {
+        if constexpr (BF16 && HT == 1 && HTN == 4) {
+            // 32 x 128 wave tile in the two-set loop (the split mode: a wave fetches only ITS 32 weight rows, half the
+            // bytes per MFMA through the L1 return path that bounds these kernels; B fragments one column block ahead)
+            BFrag f[2];
+            read_b(xsb, off, 1, f[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile14(a, 0, bpre);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(xsb, off, 2, f[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile14(a, 1, f[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(xsb, off, 3, f[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile14(a, 2, f[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(xsb, offn, 0, bpre);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile14(a, 3, f[1]);
+        } else if constexpr (BF16) {
             BFrag f1;
             read_b(xsb, off, 1, f1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1096,7 +1128,7 @@ __global__ __launch_bounds__(64 * WM * WN, TAPS > 0 ? (HT * HTN > 4 || WM * WN >
                 if (cur.nact & 1) {
                     if constexpr (BF16) {
 #pragma unroll
-                        for (int i = 0; i < (SPLIT ? 4 : 2); ++i) {
+                        for (int i = 0; i < (SPLIT ? 2 : 1) * HT; ++i) {
                             asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].x) : "v"(a1.q[i].x));
                             asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].y) : "v"(a1.q[i].y));
                             asm volatile("v_mov_b32 %0, %1" : "=v"(a0.q[i].z) : "v"(a1.q[i].z));
@@ -1188,8 +1220,13 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
     const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (p.wb_split) {
+#if K82_SPLIT_14
+        if (p.act == ACT_SNAKE) launch_epi<4, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
+        else launch_epi<4, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
+#else
         if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_SPLIT>(p, epi, grid, s);
         else launch_epi<2, 2, false, PREC_SPLIT>(p, epi, grid, s);
+#endif
     } else {
         if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_BF16>(p, epi, grid, s);
         else launch_epi<2, 2, false, PREC_BF16>(p, epi, grid, s);
