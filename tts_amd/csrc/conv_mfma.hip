@@ -35,9 +35,6 @@
 #ifndef K82_SMALL_GRID
 #define K82_SMALL_GRID 512          // fp32 launches whose 128 x 128 tiles would not fill the persistent grid use 64 x 64 tiles
 #endif
-#ifndef K82_BPIPE
-#define K82_BPIPE 1                 // fp32 tap loop: B fragments requested a whole tap ahead (0: the compiler's read-wait-multiply order)
-#endif
 #ifndef K82_EPI_FAST
 #define K82_EPI_FAST 1              // lean epilogue for interior tiles (0: the general path everywhere)
 #endif
@@ -47,17 +44,11 @@
 #ifndef K82_TRACE
 #define K82_TRACE 0                 // 1: phase time stamps (tools/trace_conv.py); never in the shipped library
 #endif
-#ifndef K82_STAGE_FAST
-#define K82_STAGE_FAST 0            // 1: staging without validity selects for interior tiles -- 40 fewer vector instructions per ci-tile, measured 1.5 % SLOWER (profiles/r02_ab_stage_fast.txt)
-#endif
 #ifndef K82_RING_SMEM
 #define K82_RING_SMEM 1             // ring pipeline: per-channel staging parameters through the scalar cache (0: vector loads, A/B only)
 #endif
 #ifndef K82_RING_WN
 #define K82_RING_WN 2               // ring pipeline: 2 = large launches run 4 x 2 waves on 128 x 256 tiles (1: always 4 x 1)
-#endif
-#ifndef K82_SPLIT_14
-#define K82_SPLIT_14 1              // bf16x3: 4 x 1 waves of 32 x 128 in the two-set loop (0: 2 x 2 waves of 64 x 64)
 #endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
@@ -309,8 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     // offset = beta - mean * scale: within 2 ulp of the reference's (x - mean) * rstd * (1 + gamma) + beta),
     // LeakyReLU is max(u, slope * u) (slope in [0, 1], checked on the host), validity is one unsigned
     // compare against the row length (0 for padded channels).
-    auto write_tile_impl = [&](auto interior_c, const Tile& T, int ci0, float* dst) {
-        constexpr bool INTERIOR = decltype(interior_c)::value;     // every staged column and channel is real: no validity selects
+    auto write_tile = [&](const Tile& T, int ci0, float* dst) {
         float out[CPW][NCOL][4];
         // (Measured and not kept: touching the per-channel parameters with an opaque asm here so that "scale = rstd * (1 +
         // gamma)" is computed behind the tap's MFMAs -- instruction selection places it right behind the loads, in front
@@ -334,8 +324,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                         floatx2 u = fma2(v2[h], (floatx2)(sc), (floatx2)(of));
                         if constexpr (SNAKE) u = snake2(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
                         else { const floatx2 w = u * slope; u.x = fmaxf(u.x, w.x); u.y = fmaxf(u.y, w.y); }
-                        out[cc][k][2 * h] = (INTERIOR || t + 2 * h < lin) ? u.x : 0.f;      // t < 0 wraps to a huge unsigned: also invalid
-                        out[cc][k][2 * h + 1] = (INTERIOR || t + 2 * h + 1 < lin) ? u.y : 0.f;
+                        out[cc][k][2 * h] = (t + 2 * h < lin) ? u.x : 0.f;      // t < 0 wraps to a huge unsigned: also invalid
+                        out[cc][k][2 * h + 1] = (t + 2 * h + 1 < lin) ? u.y : 0.f;
                     }
                 } else {
                     const float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
@@ -344,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                         float u = fmaf(v[e], sc, of);
                         if constexpr (SNAKE) u = snake_fast(u, alr[cc] * kInvTwoPi, ialr[cc]);
                         else u = fmaxf(u, u * slope);
-                        out[cc][k][e] = (INTERIOR || t + e < lin) ? u : 0.f;
+                        out[cc][k][e] = (t + e < lin) ? u : 0.f;
                     }
                 }
             }
@@ -382,16 +372,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                 }
         }
     };
-    // Interior tiles (every column the taps read lies inside the sentence, every channel of the ci-tile is real) skip the
-    // validity selects: 2 of the ~13 vector instructions per element pair, and every vector instruction of the staging
-    // step is issue time the SIMD's fp32 MFMAs do not get (tools/ubench_coissue.hip).  Same values either way.
-    auto write_tile = [&](const Tile& T, int ci0, float* dst) {
-#if K82_STAGE_FAST
-        if (T.tbase >= 0 && T.tbase + WP <= T.Lin && ci0 + KC <= p.cin) write_tile_impl(std::true_type{}, T, ci0, dst);
-        else
-#endif
-            write_tile_impl(std::false_type{}, T, ci0, dst);
-    };
+    // (Measured and not kept: a second copy of this step without the validity selects for interior tiles -- 40 of ~170
+    // vector instructions fewer per ci-tile, 1.5 % SLOWER on configs[1]; profiles/r02_ab_stage_fast.txt.)
 
     // Two sets of A fragments: the one being consumed and the one being loaded.  fp32: f[kk][mi] scalars;
     // bf16 modes: q[] are the lane's 16-byte fragments exactly as loaded (q[mi], or q[2 mi] = hi / q[2 mi + 1] = lo
@@ -521,7 +503,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             __builtin_amdgcn_sched_barrier(0);
             mma_half(a, 1, f1);
         } else {
-#if K82_BPIPE
             // All B fragments of the tap are requested up front (k-step 0 came with the previous tap), one ds_read_b32
             // each off ONE address register: fp32 MFMAs share the SIMD's vector issue with every VALU instruction
             // (tools/ubench_coissue.hip: time adds, ~5 cycles per instruction, ~20 for one that sits alone between two
@@ -544,20 +525,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], bb[kk][1], acc[1][1], 0, 0, 0);
                 }
             }
-#else
-            const float* xsp = xsb + lhi * WP + nw + l31 + off;
-#pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                const float b0 = xsp[2 * kk * WP];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b0, acc[0][0], 0, 0, 0);
-                if constexpr (HT == 2) {
-                    const float b1 = xsp[2 * kk * WP + 32];
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], b1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], b1, acc[1][1], 0, 0, 0);
-                }
-            }
-#endif
         }
     };
 
@@ -1077,9 +1044,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             ASet& Y = a1;
             TR(2);
             if constexpr (BF16) read_b(xsb, tap * p.dil + cur.shift, 0, bpre);
-#if K82_BPIPE
             else read_b32(xsb + lhi * WP + nw + l31 + tap * p.dil + cur.shift, 0, bpf);
-#endif
             {
                 {   // first active tap: stage + compute
                     const bool single = cur.nact == 1;
@@ -1220,14 +1185,10 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
     const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (p.wb_split) {
-#if K82_SPLIT_14
+        // 4 x 1 waves of 32 x 128 in the two-set loop (2 x 2 waves of 64 x 64: 2.1 % slower, profiles/r02_ab_split_32x128.txt)
         // (4 x 2 waves on 128 x 256 tiles for large launches, as the plain-bf16 ring does: 4474 vs 4475 audio-s/s, not kept)
         if (p.act == ACT_SNAKE) launch_epi<4, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
         else launch_epi<4, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
-#else
-        if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_SPLIT>(p, epi, grid, s);
-        else launch_epi<2, 2, false, PREC_SPLIT>(p, epi, grid, s);
-#endif
     } else {
         if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_BF16>(p, epi, grid, s);
         else launch_epi<2, 2, false, PREC_BF16>(p, epi, grid, s);
