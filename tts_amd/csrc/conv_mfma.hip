@@ -50,6 +50,9 @@
 #ifndef K82_RING_WN
 #define K82_RING_WN 2               // ring pipeline: 2 = large launches run 4 x 2 waves on 128 x 256 tiles (1: always 4 x 1)
 #endif
+#ifndef K82_F32_HWSIN
+#define K82_F32_HWSIN 0             // 1: v_sin_f32 in the fp32 Snake (+0.6 % on configs[1], all parity tests green, 1e-6 absolute; not taken)
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -322,7 +325,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         floatx2 u = fma2(v2[h], (floatx2)(sc), (floatx2)(of));
+#if K82_F32_HWSIN
+                        if constexpr (SNAKE) {      // hardware sine (argument in revolutions, reduced with v_fract)
+                            const floatx2 xr = u * (alr[cc] * kInvTwoPi);
+                            floatx2 sn;
+                            sn.x = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(xr.x));
+                            sn.y = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(xr.y));
+                            u = fma2((floatx2)(ialr[cc]), sn * sn, u);
+                        }
+#else
                         if constexpr (SNAKE) u = snake2(u, alr[cc], ialr[cc]);   // (hw sin in fp32 mode: +1 %, not taken)
+#endif
                         else { const floatx2 w = u * slope; u.x = fmaxf(u.x, w.x); u.y = fmaxf(u.y, w.y); }
                         out[cc][k][2 * h] = (t + 2 * h < lin) ? u.x : 0.f;      // t < 0 wraps to a huge unsigned: also invalid
                         out[cc][k][2 * h + 1] = (t + 2 * h + 1 < lin) ? u.y : 0.f;
