@@ -15,7 +15,8 @@
 // time in un-overlapped prologues and epilogues.
 // Pipeline: the x tile is double-buffered in LDS -- the raw global loads of ci-tile i+1 are issued
 // into registers at the first tap of tile i and transformed + written to the other buffer right
-// after that tap's MFMAs are issued, one barrier per ci-tile.  The A operand (weights) goes
+// after that tap's MFMAs are issued; one barrier per ci-tile, or (two-set loop, fp32 / bf16x3) a third buffer and a
+// step counter instead of it (LDS3 below).  The A operand (weights) goes
 // global->VGPR directly (lane l reads w[tap][ci0+2kk+(l>>5)][m+(l&31)], two 128-B segments,
 // L2-resident) and is prefetched one whole tap (16 registers) ahead of the MFMAs that consume it,
 // across ci-tile boundaries too.  B operand: ds_read_b32 of
@@ -52,6 +53,9 @@
 #endif
 #ifndef K82_F32_HWSIN
 #define K82_F32_HWSIN 0             // 1: v_sin_f32 in the fp32 Snake (+0.6 % on configs[1], all parity tests green, 1e-6 absolute; not taken)
+#endif
+#ifndef K82_LDS3
+#define K82_LDS3 1                  // two-set loop: three x-tile buffers + a step counter instead of the per-ci-tile barrier (fp32 +0.5 %, bf16x3 +1.6 %)
 #endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
@@ -194,7 +198,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     constexpr int PATCH = 32 * 36 + 64;        // per-wave epilogue patch [32][36] + the wave's 64 bias values
     static_assert(KC % NW == 0, "KC must be a multiple of the wave count");
     // ONE __shared__ object (a second one beside the staging array can cost a vmcnt(0) per k-step)
-    __shared__ __attribute__((aligned(16))) float lds[2 * KC * WP + NW * PATCH];
+    // LDS3 (fp32 / bf16x3 two-set loop, 2 x 2 and 4 x 1 waves): THREE x-tile buffers and a counter instead of the barrier --
+    // a wave signals "my share of tile g+1 is staged" right after its first tap and only waits, a whole ci-tile later,
+    // for all NW signals of that step.  Safe with three buffers: a wave that stages tile g+2 (into the buffer of tile
+    // g-1) has seen every wave's step-g signal, and a wave's LDS instructions execute in order, so every read of tile
+    // g-1 is behind that signal.
+    constexpr bool LDS3 = K82_LDS3 && TAPS == 0 && PREC != PREC_BF16 && WM >= 2;
+    constexpr int NBUF = LDS3 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * KC * WP + NW * PATCH + 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: Tile stays in SGPRs
     const int wm = wave / WN, wn = wave % WN;
@@ -204,7 +215,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     const int MT = p.cout_p / BM, NT = (p.Lmax_out + BN - 1) / BN;
     const int total = MT * NT * p.B, G = gridDim.x;
     const unsigned tapall = (p.taps >= 32) ? 0xffffffffu : ((1u << p.taps) - 1u);
-    float* const patch = lds + 2 * KC * WP + wave * PATCH;
+    float* const patch = lds + NBUF * KC * WP + wave * PATCH;
+    unsigned* const stepcnt = reinterpret_cast<unsigned*>(lds + NBUF * KC * WP + NW * PATCH);
     float* const bsh = patch + 32 * 36;
 #if K82_TRACE
     // phase time stamps of every wave (tools/trace_conv.py reads them): event = id << 56 | s_memtime
@@ -1018,11 +1030,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     // round-robin order, which spreads neighbouring tiles over all eight L2s and memory channels; kept simple.)
     int q = next_valid(blockIdx.x, cur);
     if (q < 0) return;
+    if (LDS3 && tid == 0) *stepcnt = 0u;
     load_tile(cur, 0);
     write_tile(cur, 0, lds);
     load_a(cur.m0, 0, cur.tap0, a0);
     __syncthreads();
-    int g = 0;                                   // parity of the LDS buffer holding the current ci-tile
+    int g = 0;                                   // ci-tile steps done: buffer g % NBUF holds the current ci-tile
+    int bcur = 0, bnxt = 1;
     while (true) {
         const int qn = next_valid(q + G, nxt);
         const bool have_next = qn >= 0;
@@ -1038,8 +1052,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
         for (int it = 0; it < ntiles; ++it) {
             const int ci0 = it * KC;
             const bool more = it + 1 < ntiles;
-            const float* xsb = lds + (g & 1) * (KC * WP);
-            float* xsn = lds + ((g + 1) & 1) * (KC * WP);
+            const float* xsb = lds + bcur * (KC * WP);
+            float* xsn = lds + bnxt * (KC * WP);
             Tile S;                                           // whose x tile / weights come next (by value:
             S.b = more ? cur.b : nxt.b;                       // a reference to "cur or nxt" sends both to scratch)
             S.m0 = more ? cur.m0 : nxt.m0;
@@ -1073,6 +1087,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                     TR(8);
 #endif
                     write_tile(S, sci0, xsn);
+                    if constexpr (LDS3) {
+                        // (asm: through the generic pointer the compiler makes these FLAT operations with a vmcnt(0) wait)
+                        if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"((unsigned)(size_t)stepcnt), "v"(1u) : "memory");
+                    }
                     TR(4);
                     tap = ntap;
                 }
@@ -1124,8 +1142,23 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             // raw barrier: LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e. wait here for the
             // weight fragments just requested for the next ci-tile.
             TR(5);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ++g;
+            if constexpr (LDS3) {
+                const unsigned target = (unsigned)(NW * g);
+                // (bounded at ~10 ms: every wave reaches every step, so the bound is never met; it only keeps a bug from hanging the GPU)
+                for (int spin = 0; spin < (1 << 16); ++spin) {
+                    unsigned seen;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"((unsigned)(size_t)stepcnt) : "memory");
+                    if (__builtin_amdgcn_readfirstlane(seen) >= target) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                bcur = bnxt;
+                bnxt = bnxt == NBUF - 1 ? 0 : bnxt + 1;
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                bcur ^= 1; bnxt ^= 1;
+            }
         }
         TR(6);
         epilogue(cur, bias_l);
