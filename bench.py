@@ -149,7 +149,7 @@ def main():
         # HBM bytes per launch of the dominant kernel family come from the committed rocprofv3 PMC passes of this
         # same command (counters cannot be read from inside the process); see profiles/*_traffic.json.
         traffic, traffic_src = None, None
-        tname = {"fp32": "r02_v3_traffic.json", "bf16x3": "r02_v3_traffic_bf16x3.json"}.get(args.dtype)
+        tname = {"fp32": "r02_v5_traffic.json", "bf16x3": "r02_v5_traffic_bf16x3.json"}.get(args.dtype)
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname or "")
         if tname and os.path.exists(tp) and B == 64 and T == 256:
             with open(tp) as fh:
@@ -178,7 +178,7 @@ def main():
                        "parallelism": f"dp{world} (sentence sharding, no data-path collective)",
                        "audio_finite": finite},
             "roofline": {
-                "kernel": "conv_mfma_kernel<2,2> (implicit-GEMM Conv1d, " + ("v_mfma_f32_32x32x16_bf16)" if bf16 else "v_mfma_f32_32x32x2_f32)"),
+                "kernel": "conv_mfma_kernel, 128-row family (implicit-GEMM Conv1d; " + ("4x1 / 4x2 / 2x2 waves, v_mfma_f32_32x32x16_bf16)" if bf16 else "2x2 waves, v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                 "peak": peak_tf,

@@ -33,10 +33,7 @@ out = {"command": f"rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 1 --w
        "kernels": {}}
 n = f_sum = w_sum = 0.0
 for k in sorted(fetch):
-    if "<2, 2," not in k:
-        fam = False
-    else:
-        fam = True
+    fam = "conv_mfma_kernel" in k and "<1, 4," not in k      # the 128-row family: 2x2, 4x1 and 4x2 wave shapes (not the 64-row 1x4 kernel)
     fv, wv = fetch[k], write.get(k, [])
     out["kernels"][k] = {"launches": len(fv), "FETCH_SIZE_KB_mean": sum(fv) / len(fv),
                          "WRITE_SIZE_KB_mean": (sum(wv) / len(wv)) if wv else None}
