@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                 for (int spin = 0; spin < (1 << 16); ++spin) {
                     unsigned seen;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"((unsigned)(size_t)stepcnt) : "memory");
-                    if (__builtin_amdgcn_readfirstlane(seen) >= target) break;
+                    if ((unsigned)__builtin_amdgcn_readfirstlane((int)seen) >= target) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 asm volatile("" ::: "memory");
