@@ -58,6 +58,9 @@
 #ifndef K82_LDS3
 #define K82_LDS3 1                  // two-set loop: three x-tile buffers + a step counter instead of the per-ci-tile barrier (fp32 +0.5 %, bf16x3 +1.6 %)
 #endif
+#ifndef K82_F32_BM256
+#define K82_F32_BM256 1             // fp32, >= 256 output channels, large launches: 256 x 128 workgroup tiles (+1.6 % on configs[1])
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     // arithmetic runs on the scalar unit and the loads use the saddr form -- vector instructions in the tap loop
     // compete with the MFMAs for issue, scalar ones do not.
     const unsigned a_lane = BF16 ? (unsigned)((lhi * p.cout_p + l31) * (SPLIT ? 32 : 16))
-                            : (WM == 2 && WN == 2) ? (unsigned)((lhi * p.cout_p + l31) * 32)
+                            : (WN == 2) ? (unsigned)((lhi * p.cout_p + l31) * 32)
                                                    : (unsigned)((lhi * p.cout_p + l31) * 4);
     auto load_a = [&](int m0, int ci0, int tap, ASet& a) {
         if constexpr (BF16) {
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             const uint4* wp = reinterpret_cast<const uint4*>(base + a_lane);
             if constexpr (SPLIT) { a.q[0] = wp[0]; a.q[1] = wp[1]; if constexpr (HT == 2) { a.q[2] = wp[64]; a.q[3] = wp[65]; } }
             else { a.q[0] = wp[0]; if constexpr (HT == 2) a.q[1] = wp[32]; }
-        } else if constexpr (WM == 2 && WN == 2) {              // (both wave-tile sizes)
+        } else if constexpr (WN == 2) {                         // 2 x 2 and 4 x 2 waves (both wave-tile sizes)
             // fragment image: the lane's 8 k-step values of a row are 32 contiguous bytes -- 4 x 16-byte loads per
             // tap instead of 16 dword loads
             const char* base = reinterpret_cast<const char*>(p.wf) +
@@ -1283,7 +1286,13 @@ void launch_conv(const ConvP& p, hipStream_t s) {
             const unsigned grid = (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks);
             if (p.taps == 1 && (epi == EPI_PLAIN || epi == EPI_RES)) launch_shape<2, 2, 1, 32>(p, epi, grid, s);
             else launch_shape<2, 2, 1>(p, epi, grid, s);
-        } else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
+        }
+#if K82_F32_BM256
+        // >= 256 output channels, large launches: 4 x 2 waves on 256 x 128 tiles, one workgroup per CU -- the staged x tile
+        // (and its vector work, which excludes the fp32 MFMAs) is shared by twice the rows
+        else if (p.cout_p % 256 == 0 && total >= 4 * 256) launch_shape<4, 2>(p, epi, 256u, s);
+#endif
+        else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
         launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
