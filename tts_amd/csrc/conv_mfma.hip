@@ -61,6 +61,12 @@
 #ifndef K82_F32_BM256
 #define K82_F32_BM256 1             // fp32, >= 256 output channels, large launches: 256 x 128 workgroup tiles (+1.6 % on configs[1])
 #endif
+#ifndef K82_SPLIT_BM256
+#define K82_SPLIT_BM256 1           // bf16x3, >= 256 output channels, large launches: 256 x 128 tiles, 8 x 1 waves (+2.5 % on configs[1])
+#endif
+#ifndef K82_RING_BM256
+#define K82_RING_BM256 1            // bf16 ring, >= 256 output channels, large launches: 256 x 128 tiles, 8 x 1 waves (+1.5 % on configs[1])
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -1204,6 +1210,17 @@ static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // missed on, and the x halo is shared by twice the columns: +2.9 % on configs[1] in bf16 (6972 -> 7173 audio-s/s,
     // profiles/r02_ab_ring_wn2_bf16.txt); single launches of the shapes lose 3-7 % at k >= 7 and the book workloads do
     // not move, so launches with fewer than two rounds of 256-column tiles keep 4 x 1 waves and two workgroups per CU.
+#if K82_RING_BM256
+    if (p.cout_p % 256 == 0 && total >= 4 * 256) {          // 256 x 128 tiles, 8 x 1 waves, one workgroup per CU
+        if (p.taps == 3) {
+            if (snake) launch_epi<8, 1, true, PREC, 1, 16, 3, 4>(p, epi, 256u, s);
+            else launch_epi<8, 1, false, PREC, 1, 16, 3, 4>(p, epi, 256u, s);
+            return true;
+        }
+        if (snake && p.taps == 7) { launch_epi<8, 1, true, PREC, 1, 16, 7, 4>(p, epi, 256u, s); return true; }
+        if (snake && p.taps == 11) { launch_epi<8, 1, true, PREC, 1, 16, 11, 4>(p, epi, 256u, s); return true; }
+    }
+#endif
     const long t256 = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 128) * p.B;
     if (K82_RING_WN == 2 && t256 >= 2 * 256) {
         const unsigned grid = 256;
@@ -1237,6 +1254,13 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
     if (p.wb_split) {
         // 4 x 1 waves of 32 x 128 in the two-set loop (2 x 2 waves of 64 x 64: 2.1 % slower, profiles/r02_ab_split_32x128.txt)
         // (4 x 2 waves on 128 x 256 tiles for large launches, as the plain-bf16 ring does: 4474 vs 4475 audio-s/s, not kept)
+#if K82_SPLIT_BM256
+        if (p.cout_p % 256 == 0 && total >= 4 * 256) {      // as fp32: 256 x 128 tiles (8 x 1 waves), one workgroup per CU
+            if (p.act == ACT_SNAKE) launch_epi<8, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
+            else launch_epi<8, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
+            return;
+        }
+#endif
         if (p.act == ACT_SNAKE) launch_epi<4, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
         else launch_epi<4, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
     } else {
