@@ -597,3 +597,29 @@ def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
                 eng.close()
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
         assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+def test_256_row_tiles_give_the_128_row_tiles_bits(monkeypatch, precision):
+    """Large launches with >= 256 output channels run 256 x 128 workgroup tiles (4 x 2 / 8 x 1 waves, one workgroup per
+    CU, the staged x tile shared by twice the rows; conv_mfma.hip launch_conv / launch_bf16 / launch_ring).  Every
+    output element is still summed in the same order, so an engine built with K82_BM256=0 must reproduce durations
+    and audio exactly.  The batch is long enough for the 256-channel generator stage to take the large tiles."""
+    from tts_amd.engine import Engine
+    id_lists, ref_s = H.make_batch(17, [37, 90, 12, 200, 65])
+    seeds = np.arange(5, dtype=np.uint64) + 11
+    out = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("K82_BM256", sw)
+        eng = Engine(spec.synthetic_state_dicts(0), precision=precision)
+        try:
+            ids, lens = eng.pack(id_lists)
+            with eng.session():
+                pred, _ = eng.durations(ids, lens, ref_s)
+                audio, off = eng.decode(seeds=seeds)
+            out.append((pred, audio.copy(), off))
+        finally:
+            eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())

@@ -1211,7 +1211,7 @@ static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // profiles/r02_ab_ring_wn2_bf16.txt); single launches of the shapes lose 3-7 % at k >= 7 and the book workloads do
     // not move, so launches with fewer than two rounds of 256-column tiles keep 4 x 1 waves and two workgroups per CU.
 #if K82_RING_BM256
-    if (p.cout_p % 256 == 0 && total >= 4 * 256) {          // 256 x 128 tiles, 8 x 1 waves, one workgroup per CU
+    if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) {          // 256 x 128 tiles, 8 x 1 waves, one workgroup per CU
         if (p.taps == 3) {
             if (snake) launch_epi<8, 1, true, PREC, 1, 16, 3, 4>(p, epi, 256u, s);
             else launch_epi<8, 1, false, PREC, 1, 16, 3, 4>(p, epi, 256u, s);
@@ -1255,7 +1255,7 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
         // 4 x 1 waves of 32 x 128 in the two-set loop (2 x 2 waves of 64 x 64: 2.1 % slower, profiles/r02_ab_split_32x128.txt)
         // (4 x 2 waves on 128 x 256 tiles for large launches, as the plain-bf16 ring does: 4474 vs 4475 audio-s/s, not kept)
 #if K82_SPLIT_BM256
-        if (p.cout_p % 256 == 0 && total >= 4 * 256) {      // as fp32: 256 x 128 tiles (8 x 1 waves), one workgroup per CU
+        if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) {      // as fp32: 256 x 128 tiles (8 x 1 waves), one workgroup per CU
             if (p.act == ACT_SNAKE) launch_epi<8, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
             else launch_epi<8, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
             return;
@@ -1314,7 +1314,7 @@ void launch_conv(const ConvP& p, hipStream_t s) {
 #if K82_F32_BM256
         // >= 256 output channels, large launches: 4 x 2 waves on 256 x 128 tiles, one workgroup per CU -- the staged x tile
         // (and its vector work, which excludes the fp32 MFMAs) is shared by twice the rows
-        else if (p.cout_p % 256 == 0 && total >= 4 * 256) launch_shape<4, 2>(p, epi, 256u, s);
+        else if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) launch_shape<4, 2>(p, epi, 256u, s);
 #endif
         else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
     } else {

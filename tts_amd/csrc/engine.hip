@@ -211,6 +211,7 @@ struct k82_handle {
     int lstm_err_h = 0;
     int cus = 0;
     bool ring_off = false;             // K82_RING=0: the bf16 modes keep the generic tap loop (A/B and bit-identity tests only)
+    bool bm256_off = false;            // K82_BM256=0: no 256 x 128 workgroup tiles (bit-identity tests only)
     bool fused_stats = true;           // K82_FUSED_STATS=0: every instance-norm statistic from the sweep kernel (A/B only)
     int lstm_split_max_b = 0;          // set in finalize(): CUs / 2 (K82_LSTM_SPLIT_MAX_B=0 selects the streaming kernel everywhere)
     int lstm_spin_limit = 1 << 18;     // polls a split-LSTM workgroup waits for a partner's h (K82_LSTM_SPIN_LIMIT: test hook)
@@ -623,6 +624,7 @@ struct k82_handle {
             lstm_split_max_b = cus / 2;          // 4 sentences per workgroup: one resident round up to CUs / 2 sentences
             if (const char* e = std::getenv("K82_FUSED_STATS")) fused_stats = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_RING")) ring_off = std::atoi(e) == 0;
+            if (const char* e = std::getenv("K82_BM256")) bm256_off = std::atoi(e) == 0;
             // K82_LSTM_SPLIT_MAX_B=0: streaming kernel everywhere -- for deployments that KNOW the GPU is shared
             if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));
             if (const char* e = std::getenv("K82_LSTM_SPIN_LIMIT")) lstm_spin_limit = std::max(0, std::atoi(e));   // test hook
@@ -650,7 +652,7 @@ struct k82_handle {
         p.out_scale = 1.f; p.acc_scale = 1.f;
         p.up_s = w.up_s; p.up_cout_shift = w.up_shift; p.tapmask = w.tapmask;
         p.B = nb; p.Lmax_out = Lmax;
-        p.dbg = ring_off ? 1 : 0;
+        p.dbg = (ring_off ? 1 : 0) | (bm256_off ? 2 : 0);
         return p;
     }
     // operand shapes the kernel and its grid assume (conv_mfma.hip launch_conv), checked before every launch

@@ -49,7 +49,7 @@ struct ConvP {
     int up_s, up_cout_shift, up_off;
     const unsigned* tapmask;                   // per 64-row M tile: bitmask of non-zero taps (nullptr: all)
     int B, Lmax_out;                           // grid extents
-    int dbg;                                   // 1: never take the ring pipeline of the bf16 modes (K82_RING=0, A/B and bit-identity tests)
+    int dbg;                                   // test switches of the engine: bit 0 = no ring pipeline (K82_RING=0), bit 1 = no 256 x 128 tiles (K82_BM256=0)
     unsigned long long* trace;                 // K82_TRACE builds only (tools/trace_conv.py): per-wave phase time stamps; nullptr otherwise
     // instance-norm partials of the stored output (wide epilogues only): stat[b*sbs + m*snt + t/32] = (sum y, sum y^2)
     // over the valid columns of the 32-column span; every entry is written by exactly one wave (no atomics), and the
