@@ -1253,7 +1253,8 @@ static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {   
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (p.wb_split) {
         // 4 x 1 waves of 32 x 128 in the two-set loop (2 x 2 waves of 64 x 64: 2.1 % slower, profiles/r02_ab_split_32x128.txt)
-        // (4 x 2 waves on 128 x 256 tiles for large launches, as the plain-bf16 ring does: 4474 vs 4475 audio-s/s, not kept)
+        // (4 x 2 waves on 128 x 256 tiles for large launches, as the plain-bf16 ring does: 4474 vs 4475 audio-s/s with the
+        // barrier, 4615 vs 4662 with the step counter; not kept)
 #if K82_SPLIT_BM256
         if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) {      // as fp32: 256 x 128 tiles (8 x 1 waves), one workgroup per CU
             if (p.act == ACT_SNAKE) launch_epi<8, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
