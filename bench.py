@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the B = 1 latency loop and the other-precision legs")
+    ap.add_argument("--latency-sentences", type=int, default=45)
     ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32",
                     help="fp32 (BASELINE configs[1], the default); bf16 MFMA in the decoder/generator (cfg3's dtype); "
                          "bf16x3: the same convolutions with split operands, three bf16 MFMAs per product (fp32-grade)")
@@ -134,6 +136,12 @@ def main():
                 fam[name].update({"bound": "latency", "sentence_steps_per_s": w / (ms * 1e-3)})
     eng.prof_enable(False)
 
+    # ---- the rest of BASELINE.json's metric, outside the timed region (rank 0 of an N = 1 run only): the same step in the
+    # other two precision modes, and "p50 first-audio ms" -- one sentence at a time, B = 1, call -> float32 PCM on the host
+    extra = {}
+    if world == 1 and not args.no_extras:
+        extra = extras(eng, args, step, audio_s=total / spec.SAMPLE_RATE)
+
     audio_s = total / spec.SAMPLE_RATE
     per_rank = [[dt, audio_s]]
     if world > 1:                      # every rank's (seconds, audio-seconds per step): value uses the SLOWEST rank's time
@@ -192,6 +200,7 @@ def main():
                 "algorithmic_flops_per_step": conv_flops / args.steps,
             },
             "other_kernels": fam,
+            **extra,
         }
         assert len(per_rank) == args.gpus == world
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0, N = 1 only
@@ -201,6 +210,67 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(eng, args, step, audio_s):
+    """Extra keys of the JSON line (BASELINE.json metric: "...; p50 first-audio ms"; configs[2] is quoted in bf16).
+
+    first_audio_ms_*: configs[4] -- sentences one at a time (B = 1) through Engine.synthesize, host ids in, float32 PCM on
+    the host out; lengths follow the first sentences of Sound-of-Sirens.epub (tests/golden/epub_sound_of_sirens.json.gz
+    holds the character lengths only; the phoneme ids are synthetic, one per character, as everywhere in this bench); the
+    first 5 calls (workspace growth) are dropped.  Play/next path: speech7.py:124-133,273-350.
+    other_dtypes: the timed step (same batch, same inputs) in the other precision modes, 1 warm-up + 2 timed steps each.
+    """
+    import gzip
+    import torch
+    from tts_amd import spec, text as T
+    out = {}
+    peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "epub_sound_of_sirens.json.gz"), "rt", encoding="utf-8") as fh:
+        lens = [min(max(int(n), 1), T.MAX_PHONEME_LENGTH) for n in json.load(fh)["char_lengths"][:args.latency_sentences]]
+    rng = np.random.default_rng(4242)
+    sent = [rng.integers(1, 178, size=n).tolist() for n in lens]
+    pack = spec.synthetic_voice_pack(1)
+
+    def latency():
+        lat, aud = [], []
+        for k, x in enumerate(sent):
+            r = T.style_row(pack, len(x), "kokoro_onnx")[None]
+            t0 = time.perf_counter()
+            audios, _ = eng.synthesize([x], r, speed=1.0, seeds=[k])
+            lat.append((time.perf_counter() - t0) * 1e3)
+            aud.append(len(audios[0]) / spec.SAMPLE_RATE)
+        lat, aud = np.array(lat[5:]), np.array(aud[5:])
+        return {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)), "mean_audio_s": float(aud.mean()),
+                "sentences": int(lat.size), "mean_tokens": float(np.mean([len(x) + 2 for x in sent[5:]]))}
+
+    first = {}
+    others = {}
+    for mode in (args.dtype,) + tuple(m for m in ("fp32", "bf16x3", "bf16") if m != args.dtype):
+        eng.set_precision(mode)
+        if mode != args.dtype:
+            step()
+            torch.cuda.synchronize()
+            eng.prof_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            ms, n, fl = eng.prof_read("conv_mfma_2x2")
+            eng.prof_enable(False)
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else None
+            others[mode] = {"value": audio_s / dt, "unit": "audio-s/s", "ms_per_step": dt * 1e3, "steps": 2,
+                            "roofline": {"bound": "mfma", "achieved": tf, "peak": peak[mode], "unit": "TFLOP/s",
+                                         "frac": tf / peak[mode] if tf else None, "ms_per_step": ms / 2}}
+        first[mode] = latency()
+    eng.set_precision(args.dtype)
+    out["first_audio_ms_p50"] = first[args.dtype]["p50"]
+    out["first_audio_ms_p95"] = first[args.dtype]["p95"]
+    out["first_audio"] = {"workload": "configs[4]: B = 1, one sentence per call, host ids in -> float32 PCM on the host; sentence lengths "
+                                      "of Sound-of-Sirens.epub (first sentences), synthetic phoneme ids", "unit": "ms", "by_dtype": first}
+    out["other_dtypes"] = others
+    return out
 
 
 def launch_ranks(n):

@@ -265,3 +265,25 @@ def test_player_synthesizes_itself_after_max_wait():
     k.release.set()
     assert done.wait(5.0)
     assert [i for i, _ in sink.played] == [0, 1]
+
+
+def test_worker_exception_fails_only_its_own_sentences_and_the_worker_goes_on():
+    """A task that raises outside create() (here: _synthesize_many itself) marks ITS sentences failed -- the player skips
+    them as after a failed create (speech7.py:336-340) -- leaves the other worker's in-flight entries alone, and both
+    workers keep serving the list: no sentence waits for max_wait, none is synthesized twice."""
+    k, sink = FakeKokoro(delay=0.01), NullSink()
+    e = TTSEngine.parallel(k, sink, debounce=0.01, max_wait=None)
+    real = e._synthesize_many
+    boom = {3}
+
+    def flaky(idxs):
+        if boom & set(idxs):
+            raise OSError("disk full")
+        return real(idxs)
+
+    e._synthesize_many = flaky
+    e.speak_sentences_list(S)
+    assert e.wait(5.0)                                         # max_wait=None: would hang if index 3 were never failed
+    assert [i for i, _ in sink.played] == [0, 1, 2, 4, 5, 6, 7, 8, 9]
+    assert sorted(k.texts()) == sorted(s for i, s in enumerate(S) if i != 3)      # exactly once each
+    assert e.fallbacks == 0

@@ -580,7 +580,7 @@ def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
     from tts_amd.engine import Engine
     # the long batch runs the generator stages on the 4 x 2-wave ring (128 x 256 tiles: launches with at least two rounds
     # of them), the short one keeps every launch on the 4 x 1-wave ring
-    for lengths in ([37, 90, 12, 200, 65], [9, 14]):
+    for lengths, wide in (([37, 90, 12, 200, 65], True), ([9, 14], False)):
         id_lists, ref_s = H.make_batch(13, lengths)
         seeds = np.arange(len(lengths), dtype=np.uint64) + 70
         out = []
@@ -588,11 +588,19 @@ def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
             monkeypatch.setenv("K82_RING", ring)
             eng = Engine(spec.synthetic_state_dicts(0), precision="bf16")
             try:
+                n0 = [eng.prof_read(k)[1] for k in ("conv_shape_ring", "conv_shape_ring_wn2")]
                 ids, lens = eng.pack(id_lists)
                 with eng.session():
                     pred, _ = eng.durations(ids, lens, ref_s)
                     audio, off = eng.decode(seeds=seeds)
                 out.append((pred, audio.copy(), off))
+                ran = [eng.prof_read(k)[1] - a for k, a in zip(("conv_shape_ring", "conv_shape_ring_wn2"), n0)]
+                # the comparison is only worth something if the "1" run really took the ring kernels (and, for the long
+                # batch, the 4 x 2-wave shape) and the "0" run did not
+                if ring == "1":
+                    assert ran[0] > 0 and (ran[1] > 0) == wide, (lengths, ran)
+                else:
+                    assert ran == [0, 0], (lengths, ran)
             finally:
                 eng.close()
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
@@ -607,19 +615,51 @@ def test_256_row_tiles_give_the_128_row_tiles_bits(monkeypatch, precision):
     output element is still summed in the same order, so an engine built with K82_BM256=0 must reproduce durations
     and audio exactly.  The batch is long enough for the 256-channel generator stage to take the large tiles."""
     from tts_amd.engine import Engine
-    id_lists, ref_s = H.make_batch(17, [37, 90, 12, 200, 65])
-    seeds = np.arange(5, dtype=np.uint64) + 11
+    lengths = [37, 90, 12, 200, 65, 180, 150, 120]      # 8 sentences: the 256-channel stage has >= 4 x CUs tiles with margin
+    id_lists, ref_s = H.make_batch(17, lengths)
+    seeds = np.arange(len(lengths), dtype=np.uint64) + 11
     out = []
     for sw in ("1", "0"):
         monkeypatch.setenv("K82_BM256", sw)
         eng = Engine(spec.synthetic_state_dicts(0), precision=precision)
         try:
+            n0 = eng.prof_read("conv_shape_bm256")[1]
             ids, lens = eng.pack(id_lists)
             with eng.session():
                 pred, _ = eng.durations(ids, lens, ref_s)
                 audio, off = eng.decode(seeds=seeds)
             out.append((pred, audio.copy(), off))
+            ran = eng.prof_read("conv_shape_bm256")[1] - n0
+            assert (ran > 0) == (sw == "1"), (precision, sw, ran)       # the large-tile family ran in one engine only
         finally:
             eng.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
     assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())
+
+
+@pytest.mark.gpu
+def test_conv_step_counter_timeout_fails_the_call(monkeypatch):
+    """The fp32 / bf16x3 conv kernels replace the per-ci-tile barrier by an LDS step counter that a wave polls with a
+    bound (conv_mfma.hip, LDS3).  A wave whose bound runs out goes on (every wave must reach the end of the grid) and may
+    read an unstaged tile -- so it must say so: the engine finds the device error word behind its stream synchronize and
+    the call fails with K82_EHIP instead of returning samples.  K82_CONV_SPIN_LIMIT=0 gives every wave that does not
+    find the counter at its target on the FIRST poll an exhausted bound; the default (65536 polls, ~10 ms) is never met."""
+    from tts_amd.engine import Engine
+    id_lists, ref_s = H.make_batch(23, [60, 41])
+    monkeypatch.setenv("K82_CONV_SPIN_LIMIT", "0")
+    eng = Engine(spec.synthetic_state_dicts(0))
+    try:
+        n0 = eng.prof_read("conv_shape_lds3")[1]
+        with pytest.raises(RuntimeError, match="step counter"):
+            for _ in range(4):                              # one pass is thousands of polls; four to be sure
+                eng.synthesize(id_lists, ref_s, seeds=[1, 2])
+        assert eng.prof_read("conv_shape_lds3")[1] > n0
+    finally:
+        eng.close()
+    monkeypatch.delenv("K82_CONV_SPIN_LIMIT")
+    eng = Engine(spec.synthetic_state_dicts(0))            # the default bound: same inputs, no error, finite audio
+    try:
+        audios, _ = eng.synthesize(id_lists, ref_s, seeds=[1, 2])
+        assert all(np.isfinite(a).all() and a.size > 0 for a in audios)
+    finally:
+        eng.close()

@@ -23,6 +23,7 @@
 // xs[2kk+(l>>5)][n+(l&31)+tap*dil], 32 consecutive floats per half-wave = conflict-free.
 // A wave owns a 64(co) x 64(t) tile = 2x2 MFMA tiles = 64 accumulator VGPRs; WM x WN waves per block.
 #include "kernels.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -1155,12 +1156,30 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             ++g;
             if constexpr (LDS3) {
                 const unsigned target = (unsigned)(NW * g);
-                // (bounded at ~10 ms: every wave reaches every step, so the bound is never met; it only keeps a bug from hanging the GPU)
-                for (int spin = 0; spin < (1 << 16); ++spin) {
+                // (bounded at ~10 ms: every wave reaches every step, so the bound is never met; it only keeps a bug from hanging
+                // the GPU.  A wave whose bound DOES run out goes on -- every wave must reach the end of the grid -- but says so
+                // in *p.err: the tile it reads next may be unstaged, and the engine fails the call instead of returning samples.)
+                // spin_limit and err are read from the kernel-argument segment on the slow path only (see epi_args: values
+                // that live in SGPRs across the main loop are spilled to VGPR lanes)
+                auto poll = [&]() -> bool {
                     unsigned seen;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"((unsigned)(size_t)stepcnt) : "memory");
-                    if ((unsigned)__builtin_amdgcn_readfirstlane((int)seen) >= target) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    return (unsigned)__builtin_amdgcn_readfirstlane((int)seen) >= target;
+                };
+                if (!poll()) {
+                    typedef const ConvP __attribute__((address_space(4))) * KArg;
+                    KArg k = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(k));
+                    const int limit = k->spin_limit;
+                    bool arrived = false;
+                    for (int spin = 1; spin < limit; ++spin) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (poll()) { arrived = true; break; }
+                    }
+                    if (!arrived) {
+                        int* e = (int*)k->err;
+                        if (e && lane == 0) *e = 2;
+                    }
                 }
                 asm volatile("" ::: "memory");
                 bcur = bnxt;
@@ -1197,6 +1216,10 @@ static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) 
     if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT, KCT>(p, epi, grid, s);
     else launch_epi<WM, WN, false, PREC_F32, HT, KCT>(p, epi, grid, s);
 }
+static std::atomic<long> g_shape_launches[CONV_NSHAPE];
+long conv_shape_launches(int shape) { return shape >= 0 && shape < CONV_NSHAPE ? g_shape_launches[shape].load() : -1; }
+static inline unsigned ncu(const ConvP& p) { return p.cus > 0 ? (unsigned)p.cus : 256u; }
+
 template <int PREC>
 static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
@@ -1210,60 +1233,65 @@ static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // missed on, and the x halo is shared by twice the columns: +2.9 % on configs[1] in bf16 (6972 -> 7173 audio-s/s,
     // profiles/r02_ab_ring_wn2_bf16.txt); single launches of the shapes lose 3-7 % at k >= 7 and the book workloads do
     // not move, so launches with fewer than two rounds of 256-column tiles keep 4 x 1 waves and two workgroups per CU.
+    const unsigned cus = ncu(p);
 #if K82_RING_BM256
-    if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) {          // 256 x 128 tiles, 8 x 1 waves, one workgroup per CU
+    if (p.cout_p % 256 == 0 && total >= 4 * (long)cus && !(p.dbg & 2)) {    // 256 x 128 tiles, 8 x 1 waves, one workgroup per CU
+        bool done = true;
         if (p.taps == 3) {
-            if (snake) launch_epi<8, 1, true, PREC, 1, 16, 3, 4>(p, epi, 256u, s);
-            else launch_epi<8, 1, false, PREC, 1, 16, 3, 4>(p, epi, 256u, s);
-            return true;
-        }
-        if (snake && p.taps == 7) { launch_epi<8, 1, true, PREC, 1, 16, 7, 4>(p, epi, 256u, s); return true; }
-        if (snake && p.taps == 11) { launch_epi<8, 1, true, PREC, 1, 16, 11, 4>(p, epi, 256u, s); return true; }
+            if (snake) launch_epi<8, 1, true, PREC, 1, 16, 3, 4>(p, epi, cus, s);
+            else launch_epi<8, 1, false, PREC, 1, 16, 3, 4>(p, epi, cus, s);
+        } else if (snake && p.taps == 7) launch_epi<8, 1, true, PREC, 1, 16, 7, 4>(p, epi, cus, s);
+        else if (snake && p.taps == 11) launch_epi<8, 1, true, PREC, 1, 16, 11, 4>(p, epi, cus, s);
+        else done = false;
+        if (done) { ++g_shape_launches[CONV_SHAPE_BM256]; ++g_shape_launches[CONV_SHAPE_RING]; return true; }
     }
 #endif
     const long t256 = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 128) * p.B;
-    if (K82_RING_WN == 2 && t256 >= 2 * 256) {
-        const unsigned grid = 256;
+    if (K82_RING_WN == 2 && t256 >= 2 * (long)cus) {
+        const unsigned grid = cus;
         if (p.taps == 3) {
             if (snake) launch_epi<4, 2, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
             else launch_epi<4, 2, false, PREC, 1, 16, 3, 4>(p, epi, grid, s);
-            return true;
-        }
-        if (!snake) return false;
-        if (p.taps == 7) { launch_epi<4, 2, true, PREC, 1, 16, 7, 4>(p, epi, grid, s); return true; }
-        if (p.taps == 11) { launch_epi<4, 2, true, PREC, 1, 16, 11, 4>(p, epi, grid, s); return true; }
-        return false;
+        } else if (!snake) return false;
+        else if (p.taps == 7) launch_epi<4, 2, true, PREC, 1, 16, 7, 4>(p, epi, grid, s);
+        else if (p.taps == 11) launch_epi<4, 2, true, PREC, 1, 16, 11, 4>(p, epi, grid, s);
+        else return false;
+        ++g_shape_launches[CONV_SHAPE_RING_WN2]; ++g_shape_launches[CONV_SHAPE_RING];
+        return true;
     }
-    const unsigned grid = (unsigned)(total < 256 * K82_OCC_RING ? total : 256 * K82_OCC_RING);     // K82_OCC_RING workgroups per CU
+    const unsigned grid = (unsigned)(total < (long)cus * K82_OCC_RING ? total : (long)cus * K82_OCC_RING);     // K82_OCC_RING workgroups per CU
     if (p.taps == 3) {
         if (snake) launch_epi<4, 1, true, PREC, 1, 16, 3, 4>(p, epi, grid, s);
         else launch_epi<4, 1, false, PREC, 1, 16, 3, 4>(p, epi, grid, s);
-        return true;
-    }
-    if (!snake) return false;
-    if (p.taps == 7) { launch_epi<4, 1, true, PREC, 1, 16, 7, 4>(p, epi, grid, s); return true; }
-    if (p.taps == 11) { launch_epi<4, 1, true, PREC, 1, 16, 11, 4>(p, epi, grid, s); return true; }
-    return false;
+    } else if (!snake) return false;
+    else if (p.taps == 7) launch_epi<4, 1, true, PREC, 1, 16, 7, 4>(p, epi, grid, s);
+    else if (p.taps == 11) launch_epi<4, 1, true, PREC, 1, 16, 11, 4>(p, epi, grid, s);
+    else return false;
+    ++g_shape_launches[CONV_SHAPE_RING];
+    return true;
 }
 static void launch_bf16(const ConvP& p, int epi, long total, hipStream_t s) {       // 2x2 shape only
     // plain bf16 only: in the split mode the ring (8 registers per tap) and the doubled B fragments spill, and the build
     // measured slower than the two-set loop (r02_ab_ring4.log)
     if (!p.wb_split && launch_ring<PREC_BF16>(p, epi, total, s)) return;
-    const long cap = 256 * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
+    const unsigned cus = ncu(p);
+    const long cap = (long)cus * (p.wb_split ? K82_OCC_SPLIT : K82_OCC_BF16);
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     if (p.wb_split) {
         // 4 x 1 waves of 32 x 128 in the two-set loop (2 x 2 waves of 64 x 64: 2.1 % slower, profiles/r02_ab_split_32x128.txt)
         // (4 x 2 waves on 128 x 256 tiles for large launches, as the plain-bf16 ring does: 4474 vs 4475 audio-s/s with the
         // barrier, 4615 vs 4662 with the step counter; not kept)
 #if K82_SPLIT_BM256
-        if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) {      // as fp32: 256 x 128 tiles (8 x 1 waves), one workgroup per CU
-            if (p.act == ACT_SNAKE) launch_epi<8, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
-            else launch_epi<8, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, 256u, s);
+        if (p.cout_p % 256 == 0 && total >= 4 * (long)cus && !(p.dbg & 2)) {      // as fp32: 256 x 128 tiles (8 x 1 waves), one workgroup per CU
+            if (p.act == ACT_SNAKE) launch_epi<8, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, cus, s);
+            else launch_epi<8, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, cus, s);
+            ++g_shape_launches[CONV_SHAPE_BM256]; ++g_shape_launches[CONV_SHAPE_LDS3];
             return;
         }
 #endif
         if (p.act == ACT_SNAKE) launch_epi<4, 1, true, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
         else launch_epi<4, 1, false, PREC_SPLIT, 1, 16, 0, 4>(p, epi, grid, s);
+        ++g_shape_launches[CONV_SHAPE_LDS3];
     } else {
         if (p.act == ACT_SNAKE) launch_epi<2, 2, true, PREC_BF16>(p, epi, grid, s);
         else launch_epi<2, 2, false, PREC_BF16>(p, epi, grid, s);
@@ -1297,8 +1325,10 @@ static void launch_conv_inner(const ConvP& p, hipStream_t s) {
 void launch_conv(const ConvP& p, hipStream_t s) {
 #endif
     if (p.Lmax_out <= 0 || p.B <= 0) return;
-    const int kMaxBlocks = 256 * K82_OCC_F32;
-    static const long small_grid = [] { const char* e = getenv("K82_SMALL_GRID"); return e ? atol(e) : (long)K82_SMALL_GRID; }();   // env: tuning only
+    const unsigned cus = ncu(p);
+    const long kMaxBlocks = (long)cus * K82_OCC_F32;
+    static const long small_env = [] { const char* e = getenv("K82_SMALL_GRID"); return e ? atol(e) : -1L; }();   // env: tuning only
+    const long small_grid = small_env >= 0 ? small_env : (long)K82_SMALL_GRID * cus / 256;
     const int epi = (p.up_s || p.res_shift) ? EPI_SCALAR : p.accbuf ? EPI_ACC : p.res ? EPI_RES : EPI_PLAIN;
     if (p.cout_p % 128 == 0) {
         const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
@@ -1315,9 +1345,12 @@ void launch_conv(const ConvP& p, hipStream_t s) {
 #if K82_F32_BM256
         // >= 256 output channels, large launches: 4 x 2 waves on 256 x 128 tiles, one workgroup per CU -- the staged x tile
         // (and its vector work, which excludes the fp32 MFMAs) is shared by twice the rows
-        else if (p.cout_p % 256 == 0 && total >= 4 * 256 && !(p.dbg & 2)) launch_shape<4, 2>(p, epi, 256u, s);
+        else if (p.cout_p % 256 == 0 && total >= 4 * (long)cus && !(p.dbg & 2)) {
+            launch_shape<4, 2>(p, epi, cus, s);
+            ++g_shape_launches[CONV_SHAPE_BM256]; ++g_shape_launches[CONV_SHAPE_LDS3];
+        }
 #endif
-        else launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);
+        else { launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s); ++g_shape_launches[CONV_SHAPE_LDS3]; }
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
         launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);

@@ -108,20 +108,21 @@ struct Arena {
     // One chunk of at least `bytes` before the first pass needs it (k82_reserve): later passes up to that size never
     // reach hipMalloc.  Nothing of a previous pass may be in use.
     void reserve(size_t bytes) {
-        if (chunks.size() == 1 && chunks[0].cap >= bytes) return;
         size_t have = 0;
         for (auto& c : chunks) have = std::max(have, c.cap);
         if (chunks.size() == 1 && have >= bytes) return;
         (void)hipDeviceSynchronize();
-        for (auto& c : chunks) (void)hipFree(c.p);
-        chunks.clear();
-        cur = 0; off = 0;
+        // the new chunk first: a reservation that does not fit leaves the arena as it was (it then grows on demand)
         Chunk c;
         c.cap = std::max(bytes, have);
         if (hipMalloc((void**)&c.p, c.cap) != hipSuccess) {
             (void)hipGetLastError();
-            throw K82Error(K82_ENOMEM, "hipMalloc of " + std::to_string(c.cap) + " bytes failed (k82_reserve)");
+            throw K82Error(K82_ENOMEM, "hipMalloc of " + std::to_string(c.cap) + " bytes failed (k82_reserve); the workspace keeps its " +
+                                           std::to_string(capacity()) + " bytes and grows on demand");
         }
+        for (auto& o : chunks) (void)hipFree(o.p);
+        chunks.clear();
+        cur = 0; off = 0;
         chunks.push_back(c);
         high = std::max(high, c.cap - c.cap / 8);
     }
@@ -207,8 +208,9 @@ struct k82_handle {
     // ---- workspace + phase-1 state
     Arena aT, aF;
     bool have_phase1 = false;
-    int* lstm_err = nullptr;           // device word: set by lstm_split_kernel if a cross-workgroup wait ran out
-    int lstm_err_h = 0;
+    int* lstm_err = nullptr;           // device words: [0] set by lstm_split_kernel if a cross-workgroup wait ran out,
+    int* conv_err = nullptr;           // [1] (= lstm_err + 1) by an LDS3 conv wave whose wait for its workgroup's step counter ran out
+    int conv_spin_limit = 1 << 16;     // polls of that wait (K82_CONV_SPIN_LIMIT: test hook)
     int cus = 0;
     bool ring_off = false;             // K82_RING=0: the bf16 modes keep the generic tap loop (A/B and bit-identity tests only)
     bool bm256_off = false;            // K82_BM256=0: no 256 x 128 workgroup tiles (bit-identity tests only)
@@ -224,9 +226,15 @@ struct k82_handle {
     // waiting for its partners (co-residency lost to another process / handle on the GPU).  The flag is cleared and
     // the next passes use the streaming kernel, which computes the same bits; the caller re-runs the pass.
     bool lstm_timed_out() {
-        if (!split_used) return false;
-        HIPCHK(hipMemcpy(&lstm_err_h, lstm_err, sizeof(int), hipMemcpyDeviceToHost));
-        if (lstm_err_h == 0) return false;
+        int e[2] = {0, 0};
+        HIPCHK(hipMemcpy(e, lstm_err, sizeof(e), hipMemcpyDeviceToHost));
+        if (e[1] != 0) {                  // not recoverable by a re-run: the kernel's own synchronisation failed
+            HIPCHK(hipMemset(conv_err, 0, sizeof(int)));
+            have_phase1 = false;
+            throw K82Error(K82_EHIP, "conv_mfma_kernel: a wave's bounded wait for its workgroup's LDS step counter ran out (the tile it "
+                                     "went on to read may have been unstaged); the results of this call were discarded");
+        }
+        if (!split_used || e[0] == 0) return false;
         HIPCHK(hipMemset(lstm_err, 0, sizeof(int)));
         lstm_stream_left = 64;
         ++lstm_fallbacks;
@@ -629,8 +637,10 @@ struct k82_handle {
             if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));
             if (const char* e = std::getenv("K82_LSTM_SPIN_LIMIT")) lstm_spin_limit = std::max(0, std::atoi(e));   // test hook
         }
-        lstm_err = (int*)wmalloc(sizeof(int));
-        HIPCHK(hipMemset(lstm_err, 0, sizeof(int)));
+        if (const char* e = std::getenv("K82_CONV_SPIN_LIMIT")) conv_spin_limit = std::max(0, std::atoi(e));   // test hook
+        lstm_err = (int*)wmalloc(2 * sizeof(int));
+        conv_err = lstm_err + 1;
+        HIPCHK(hipMemset(lstm_err, 0, 2 * sizeof(int)));
         host.clear();
         finalized = true;
     }
@@ -653,6 +663,7 @@ struct k82_handle {
         p.up_s = w.up_s; p.up_cout_shift = w.up_shift; p.tapmask = w.tapmask;
         p.B = nb; p.Lmax_out = Lmax;
         p.dbg = (ring_off ? 1 : 0) | (bm256_off ? 2 : 0);
+        p.cus = cus; p.spin_limit = conv_spin_limit; p.err = conv_err;
         return p;
     }
     // operand shapes the kernel and its grid assume (conv_mfma.hip launch_conv), checked before every launch
@@ -1328,6 +1339,10 @@ int k82_prof_read(k82_handle* h, const char* name, double* ms, int64_t* launches
         h->prof_drain();
         double m = 0, w = 0; int64_t n = 0; bool found = false;
         if (std::strcmp(name, "lstm_fallbacks") == 0) { n = h->lstm_fallbacks; found = true; }
+        // launches of the large-tile conv families since the process started (bit-identity tests assert that they ran)
+        const char* const shapes[CONV_NSHAPE] = {"conv_shape_bm256", "conv_shape_ring_wn2", "conv_shape_ring", "conv_shape_lds3"};
+        for (int i = 0; i < CONV_NSHAPE; ++i)
+            if (std::strcmp(name, shapes[i]) == 0) { n = conv_shape_launches(i); found = true; }
         // workspace of the largest pass so far / capacity held now, in bytes (sizing of k82_reserve, tests)
         if (std::strcmp(name, "arena_token") == 0) { w = (double)std::max(h->aT.high, h->aT.pass_bytes); n = (int64_t)h->aT.capacity(); found = true; }
         if (std::strcmp(name, "arena_frame") == 0) { w = (double)std::max(h->aF.high, h->aF.pass_bytes); n = (int64_t)h->aF.capacity(); found = true; }

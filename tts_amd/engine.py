@@ -86,10 +86,17 @@ class Engine:
 
     def reserve(self, batch, tokens, frames):
         """k82_reserve: size the workspace once for batches up to ``batch`` sentences x ``tokens`` tokens x ``frames``
-        predicted frames per sentence, so no later pass of that size allocates."""
+        predicted frames per sentence, so no later pass of that size allocates.  A request the handle already covers
+        is a no-op (a second front-door object on a shared engine neither re-allocates nor disturbs the state a
+        durations() call left); a request that does not fit leaves the workspace as it was and raises."""
         with self._lock:
+            want = (int(batch) * ((int(tokens) + 31) // 32 * 32), int(batch) * int(frames))
+            have = getattr(self, "_reserved", (0, 0))
+            if want[0] <= have[0] and want[1] <= have[1]:
+                return
             self._pending = None
             self._check(self.lib.k82_reserve(self.h, int(batch), int(tokens), int(frames)))
+            self._reserved = (max(want[0], have[0]), max(want[1], have[1]))
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):

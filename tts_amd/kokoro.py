@@ -18,6 +18,8 @@ from __future__ import annotations
 import os
 import re
 import threading
+import warnings
+import zlib
 from dataclasses import dataclass
 
 import numpy as np
@@ -27,6 +29,10 @@ from .engine import Engine
 from .scheduler import BatchSynthesizer
 
 SAMPLE_RATE = spec.SAMPLE_RATE
+# model ids that need no checkpoint: seeded random weights of the exact architecture (spec.synthetic_state_dicts).
+# "synthetic-calm" is the set on which two fp32 implementations stay sample-comparable free-running (every frame
+# unvoiced, duration LSTMs at default scale): the front-door parity tests run on it.
+SYNTHETIC_SETS = {"synthetic": {}, "synthetic-calm": {"lstm_gain": 1.0, "f0_gain": 1.0, "f0_bias": 0.0}}
 _engine_lock = threading.Lock()
 _engines = {}
 
@@ -54,9 +60,10 @@ def _shared_engine(key, state_dicts_fn, config, device, precision="fp32"):
 
 
 def _load_model(model_path, voices_path, device, precision="fp32"):
-    if model_path == "synthetic":
+    if model_path in SYNTHETIC_SETS:
         cfg = dict(spec.DEFAULT_CONFIG)
-        eng = _shared_engine("synthetic", lambda: spec.synthetic_state_dicts(0), cfg, device, precision)
+        kw = SYNTHETIC_SETS[model_path]
+        eng = _shared_engine(model_path, lambda: spec.synthetic_state_dicts(0, **kw), cfg, device, precision)
         voices = {"af_synthetic": spec.synthetic_voice_pack(1)}
         if voices_path and os.path.exists(voices_path):
             voices = W.load_voices(voices_path)
@@ -81,10 +88,16 @@ class Kokoro:
                  reserve=(4, 256, 2000)):
         """``reserve``: (sentences, tokens, frames per sentence) the workspace is sized for up front (k82_reserve), so
         the first sentences of a read-aloud session do not pay for workspace growth; None skips it.  The default
-        covers the look-ahead window of the readers (4-5 sentences of up to 50 s each) in 4.8 GB of the 288 GB."""
+        covers the look-ahead window of the readers (4-5 sentences of up to 50 s each) in 5.2 GB of the 288 GB
+        (k82_reserve: 0.63 MB per padded frame + 90 KB per padded token).  Best effort: every process that builds a
+        Kokoro asks for it (the reference's parent + producer child both do), so on a GPU that cannot spare the
+        memory the constructor carries on and the workspace grows on demand instead."""
         self.engine, self.config, self.vocab, self.voices = _load_model(model_path, voices_path, device, precision)
         if reserve:
-            self.engine.reserve(*reserve)
+            try:
+                self.engine.reserve(*reserve)
+            except (RuntimeError, ValueError) as e:
+                warnings.warn(f"tts_amd.Kokoro: workspace reservation {tuple(reserve)} skipped ({e}); it grows on demand")
         self.synth = BatchSynthesizer(self.engine)
 
     @classmethod
@@ -155,8 +168,9 @@ class KModel:
     """hexgrad ``KModel`` [EXT]: local paths only (no hub download offline)."""
 
     def __init__(self, repo_id=None, config=None, model=None, device: int = 0):
-        if model is None or model == "synthetic":
-            self.engine, self.config, self.vocab, _ = _load_model("synthetic", None, device)
+        self.synthetic = model is None or model in SYNTHETIC_SETS
+        if self.synthetic:
+            self.engine, self.config, self.vocab, _ = _load_model(model or "synthetic", None, device)
         else:
             cfg = W.load_config(config) if isinstance(config, str) else (config or dict(spec.DEFAULT_CONFIG))
             self.config, self.vocab = cfg, cfg.get("vocab") or dict(spec.DEFAULT_VOCAB)
@@ -204,13 +218,23 @@ class KPipeline:
         self.lang_code = lang_code
         self.voices_dir = voices_dir
         self.voices = {}
+        self.synthetic = False
         if model is True:
             pth, cfgp, vo = W.find_model_files(None, voices_dir)
-            self.model = KModel(config=cfgp, model=pth, device=device) if pth else KModel(model="synthetic", device=device)
+            if pth is None:                    # as Kokoro(...) does: never noise in place of a missing checkpoint
+                raise FileNotFoundError(
+                    "KPipeline(model=True): no Kokoro .pth checkpoint found ($KOKORO_ONNX_PATH, /app/share/kokoro-models, "
+                    "~/.local/share/kokoro-models; there is no hub download offline).  Pass model=KModel(config=..., "
+                    "model=<path>) -- or model='synthetic' for seeded random weights (benchmarks / tests only)")
+            self.model = KModel(config=cfgp, model=pth, device=device)
             if vo:
                 self.voices = W.load_voices(vo)
+        elif isinstance(model, str) and model in SYNTHETIC_SETS:
+            self.model = KModel(model=model, device=device)
+            self.synthetic = True
         elif isinstance(model, KModel):
             self.model = model
+            self.synthetic = model.synthetic
         else:
             self.model = None                  # "quiet" pipeline: phonemes only
 
@@ -225,8 +249,10 @@ class KPipeline:
         if self.voices_dir and os.path.exists(os.path.join(self.voices_dir, voice + ".pt")):
             self.voices[voice] = next(iter(W.load_voices(os.path.join(self.voices_dir, voice + ".pt")).values()))
             return self.voices[voice]
-        if self.model is not None and not self.voices:
-            self.voices[voice] = spec.synthetic_voice_pack(abs(hash(voice)) % 1000)   # synthetic mode only
+        if self.model is not None and getattr(self, "synthetic", False):
+            # synthetic weights only: a voice pack seeded by a STABLE hash of the name (str.__hash__ is salted per
+            # process: two ranks of a sharded run would draw different voices)
+            self.voices[voice] = spec.synthetic_voice_pack(zlib.crc32(voice.encode("utf-8")) % 1000)
             return self.voices[voice]
         raise KeyError(f"voice '{voice}' not found")
 

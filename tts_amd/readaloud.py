@@ -213,49 +213,48 @@ class TTSEngine:
         return cur, min(len(self._tts_sentences) - 1, cur + la)
 
     def _synthesis_worker(self, gen):
-        try:
-            while True:
-                with self._cv:
-                    while True:
-                        if self.should_stop or gen != self._gen or self._current_play_index >= len(self._tts_sentences):
-                            return
-                        cur, hi = self._window()
-                        now = time.monotonic()
-                        hold = 0.0
-                        if self._nav_time is not None:
-                            hold = self._nav_time + self.debounce - now
-                            if hold <= 0:
-                                self._nav_time, hold = None, 0.0
-                        missing = [i for i in range(cur, hi + 1)
-                                   if i not in self._audio and i not in self._failed and i not in self._inflight]
-                        if missing and hold <= 0:
-                            # the sentence being waited for goes first and alone; the rest of the window in one batch
-                            # (or, under the newest harness's policy, one sentence per task as its pool threads do)
-                            todo = [cur] if missing[0] == cur or not self.batch_window else missing
-                            if not self.batch_window:
-                                todo = [missing[0]]
-                            self._inflight |= set(todo)
-                            break
-                        self._cv.wait(timeout=hold if (missing and hold > 0) else None)
-                res = self._synthesize_many(todo)
-                with self._cv:
-                    self._inflight -= set(todo)
-                    if gen != self._gen or self.should_stop:
-                        self._discard(res.values())
+        while True:
+            with self._cv:
+                while True:
+                    if self.should_stop or gen != self._gen or self._current_play_index >= len(self._tts_sentences):
                         return
                     cur, hi = self._window()
-                    for i, a in res.items():
-                        if a is None:
-                            self._failed.add(i)
-                        elif cur - self.keep_behind <= i <= cur + self.lookahead and i not in self._audio:
-                            self._audio[i] = a
-                        else:
-                            self._discard([a])               # the user has moved on: cancel-on-navigate
+                    now = time.monotonic()
+                    hold = 0.0
+                    if self._nav_time is not None:
+                        hold = self._nav_time + self.debounce - now
+                        if hold <= 0:
+                            self._nav_time, hold = None, 0.0
+                    missing = [i for i in range(cur, hi + 1)
+                               if i not in self._audio and i not in self._failed and i not in self._inflight]
+                    if missing and hold <= 0:
+                        # the sentence being waited for goes first and alone; the rest of the window in one batch
+                        # (or, under the newest harness's policy, one sentence per task as its pool threads do)
+                        todo = [cur] if missing[0] == cur or not self.batch_window else missing
+                        if not self.batch_window:
+                            todo = [missing[0]]
+                        self._inflight |= set(todo)
+                        break
+                    self._cv.wait(timeout=hold if (missing and hold > 0) else None)
+            try:
+                res = self._synthesize_many(todo)
+            except Exception as e:                               # keep the player alive (speech7.py:261-265): THIS task's
+                print(f"[error] Synthesis worker error: {e}")    # sentences count as failed (the player skips them, as it
+                res = {i: None for i in todo}                    # does after a failed create), the worker goes on, and
+            with self._cv:                                       # the other worker's in-flight entries stay untouched
+                self._inflight -= set(todo)
+                if gen != self._gen or self.should_stop:
+                    self._discard(res.values())
                     self._cv.notify_all()
-        except Exception as e:                                   # keep the player alive (speech7.py:261-265)
-            print(f"[error] Synthesis worker error: {e}")
-            with self._cv:
-                self._inflight = set()
+                    return
+                cur, hi = self._window()
+                for i, a in res.items():
+                    if a is None:
+                        self._failed.add(i)
+                    elif cur - self.keep_behind <= i <= cur + self.lookahead and i not in self._audio:
+                        self._audio[i] = a
+                    else:
+                        self._discard([a])               # the user has moved on: cancel-on-navigate
                 self._cv.notify_all()
 
     def is_cached(self, idx):

@@ -80,6 +80,13 @@ def split_sentences_abbrev(text: str):
     return [p.replace(mark, ".").strip() for p in parts if p.replace(mark, ".").strip()]
 
 
+def stable_id_for_text(text: str) -> str:
+    """Sentence id of the reader harnesses (tts_16_3.py:32-35): the first 12 hex digits of the sha1 of the UTF-8 text --
+    the key their highlight spans and audio files are matched by."""
+    import hashlib
+    return hashlib.sha1(text.encode("utf-8")).hexdigest()[:12]
+
+
 # ------------------------------------------------------------------ phonemes -> ids (a3)
 def tokenize(phonemes: str, vocab=None):
     """Characters missing from the vocab are dropped, as both front ends do [EXT]."""
