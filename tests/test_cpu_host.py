@@ -187,6 +187,12 @@ def _rank_main_pcm(rank, world, port, n, q):
     counts = [5 + (i * 37) % 200 for i in range(n)]
     mine = S.shard_sentences(counts, world)[rank]
     local = {i: np.full(600 * (counts[i] % 7 + 1), (i - 10) / 20.0, np.float32) for i in mine}      # some clip at +-1
+    # every third sentence arrives as an int16 TENSOR, the form BatchSynthesizer(output="pcm16_device") produces (there
+    # converted by k82_pcm16 on the GPU; tests/test_gpu_epub.py checks those bytes against this host expression)
+    import torch
+    from tts_amd import wav
+    for i in mine[::3]:
+        local[i] = torch.from_numpy(wav.f32_to_s16le_array(local[i]))
     res = S.ordered_gather_pcm16(local, n)
     if rank == 0:
         q.put([(int(a[0]), int(a[-1]), a.shape[0], str(a.dtype)) for a in res])

@@ -124,3 +124,28 @@ def test_rebucketing_by_predicted_frames_does_not_change_the_audio(engine):
         assert np.array_equal(a[i][1], b[i][1]) and np.array_equal(a[i][0], b[i][0]), i
     print(f"padded/real frames: {plain.stats['padded_frames'] / plain.stats['frames']:.2f} -> "
           f"{tight.stats['padded_frames'] / tight.stats['frames']:.2f} ({tight.stats['rebucketed']} batches re-bucketed)")
+
+
+def test_device_side_pcm16_gather_gives_the_host_conversions_bytes(engine):
+    """The bulk N-GPU form of the one exchange step (ordering contract
+    basic.tts_kokoro_2_play_pause_works.py:85-124): BatchSynthesizer(output="pcm16_device") converts a batch's waveform
+    to 16-bit PCM on the GPU (k82_pcm16, device to device) and ordered_gather_pcm16 takes those device tensors as they
+    are.  Single rank here (the exchange itself is covered by the world-size-2 gloo test): the gathered bytes must equal
+    the reference expression clip(x, -1, 1) * 32767 -> '<i2' (:25) applied on the host to the float32 path's audio."""
+    from tts_amd import wav
+    from tts_amd.scheduler import ordered_gather_pcm16
+    sents = [t for _, t in _book("epub_art_of_war.json.gz")["sentences"]][100:140]
+    ids = _ids_of(sents)
+    pack = spec.synthetic_voice_pack(1)
+    rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
+    seeds = [900 + i for i in range(len(ids))]
+    host = BatchSynthesizer(engine).synthesize(ids, rows, seeds=seeds)
+    dev = BatchSynthesizer(engine, output="pcm16_device").synthesize(ids, rows, seeds=seeds)
+    assert all(torch.is_tensor(dev[i][0]) and dev[i][0].is_cuda and dev[i][0].dtype == torch.int16 for i in dev)
+    got = ordered_gather_pcm16({i: dev[i][0] for i in dev}, len(ids), device="cuda")
+    want = ordered_gather_pcm16({i: host[i][0] for i in host}, len(ids))
+    assert len(got) == len(want) == len(ids)
+    for i in range(len(ids)):
+        assert np.array_equal(host[i][1], dev[i][1])
+        assert got[i].dtype == np.int16 and np.array_equal(got[i], want[i]), i
+        assert np.array_equal(want[i], wav.f32_to_s16le_array(host[i][0]))

@@ -68,7 +68,7 @@ def test_kokoro_create_matches_the_oracle_sample_by_sample(calm):
     k = Kokoro("synthetic-calm", None)
     pack = k.get_voice_style("af_synthetic")
     n_chunks = []
-    for ph, speed in zip(PHONEMES, (1.0, 1.0, 0.8, 1.0, 1.0, 1.25)):
+    for ph, speed in zip(PHONEMES, (1.0, 1.0, 0.8, 1.0, 2.0, 1.6)):      # fast speech on the long ones: fewer frames for the CPU oracle
         got, sr = k.create(ph, voice=pack, speed=speed, is_phonemes=True, trim=False)
         want, durs, idl = _oracle(calm, ph, pack, "kokoro_onnx", speed)
         n_chunks.append(len(durs))

@@ -5,8 +5,9 @@
 
 One process per GPU; every rank computes the same deterministic partition (scheduler.shard_sentences: greedy
 longest-processing-time over a FLOP estimate), synthesizes its shard in length-bucketed batches and keeps the audio in
-host memory; the only exchange is the ordered gather of the audio to rank 0 at the end (scheduler.ordered_gather),
-timed separately.  No collective touches the forward pass.  Rank 0 prints one JSON line; wall time is the maximum over
+host memory (--gather object) or, by default, as 16-bit PCM in device memory (k82_pcm16 on the GPU right behind the
+decoder); the only exchange is the ordered gather of the audio to rank 0 at the end (scheduler.ordered_gather_pcm16:
+one int16 tensor per rank over RCCL, device to device), timed separately.  No collective touches the forward pass.  Rank 0 prints one JSON line; wall time is the maximum over
 ranks between two barriers.  Reads only committed fixtures.
 """
 import argparse
@@ -61,7 +62,8 @@ counts = [len(x) + 2 for x in ids]
 mine = shard_sentences(counts, world)[rank]
 
 eng = Engine(spec.synthetic_state_dicts(0), device=local, precision=args.dtype)
-syn = BatchSynthesizer(eng, max_batch=args.max_batch)
+# --gather pcm16: the waveform is converted to 16-bit PCM ON THE GPU (k82_pcm16) and stays there until the gather
+syn = BatchSynthesizer(eng, max_batch=args.max_batch, output="pcm16_device" if args.gather == "pcm16" else "host")
 syn.synthesize(ids[:64], rows[:64])                                    # warm-up: arena growth, first launches
 
 

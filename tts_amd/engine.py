@@ -208,6 +208,11 @@ class Engine:
         self._check(self.lib.k82_pcm16(self.h, _ptr(a), _ptr(out), a.size, None))
         return out
 
+    def pcm16_device(self, src_ptr, dst_ptr, n, stream=None):
+        """k82_pcm16 on buffers that already live on the GPU (raw device pointers: float32 in, int16 out, ``n`` samples):
+        the conversion the bulk N-GPU gather does BEFORE its one copy off the device (scheduler.ordered_gather_pcm16)."""
+        self._check(self.lib.k82_pcm16(self.h, _ptr(int(src_ptr)), _ptr(int(dst_ptr)), int(n), _ptr(stream)))
+
     def pcm16_static(self, audio, out=None):
         """k82_pcm16_static: the same conversion without any allocation on the device side (static staging array,
         at most ``K82_PCM16_STATIC_MAX`` samples per call).  ``out``: optional preallocated int16 array."""

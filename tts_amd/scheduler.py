@@ -74,7 +74,7 @@ class BatchSynthesizer:
     returns audio per sentence, in input order."""
 
     def __init__(self, engine, max_batch: int = 64, max_tokens: int = 64 * 256, frame_budget: int = 160_000,
-                 frame_pad_limit: float = 3.0):
+                 frame_pad_limit: float = 3.0, output: str = "host"):
         """Two-phase execution: batches are formed by token count, phase 1 predicts the
         durations, and a batch whose PREDICTED frame counts are too ragged -- padded frames B * Fmax above
         ``frame_pad_limit`` x the real frames, or more real frames than ``frame_budget`` -- is re-bucketed by F: its
@@ -85,6 +85,13 @@ class BatchSynthesizer:
         bucketed by tokens alone) a limit of 1.5 measured 5-9 % SLOWER than no limit (17 more, smaller batches and
         their repeated phase 1) -- hence the loose default, which only catches pathological mixes such as speed 0.5
         next to speed 2.0 (tests/test_gpu_epub.py)."""
+        if output not in ("host", "pcm16_device"):
+            raise ValueError("output must be 'host' (float32 numpy per sentence) or 'pcm16_device' (int16 torch tensors on the GPU)")
+        # "pcm16_device": the bulk form for N GPUs -- a batch's waveform never leaves the GPU as float32: k82_decode writes
+        # it into a device buffer, k82_pcm16 converts it there (clip(x, -1, 1) * 32767 -> int16, the reference's playback
+        # format: basic.tts_kokoro_2_play_pause_works.py:25), and the per-sentence results are int16 views of that device
+        # buffer, ready for ordered_gather_pcm16 to send over RCCL or copy to the host once, at half the bytes.
+        self.output = output
         self.engine = engine
         self.max_batch, self.max_tokens, self.frame_budget = max_batch, max_tokens, frame_budget
         self.frame_pad_limit = frame_pad_limit
@@ -106,7 +113,17 @@ class BatchSynthesizer:
             split = len(id_lists) > 1 and (real > self.frame_budget or padded > self.frame_pad_limit * real)
             if not split:
                 t0 = time.perf_counter()
-                audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
+                if self.output == "pcm16_device":
+                    import torch
+                    dev = torch.device("cuda", self.engine.device)
+                    n = real * spec.FRAME_SAMPLES
+                    f32 = torch.empty((n,), dtype=torch.float32, device=dev)
+                    audio = torch.empty((n,), dtype=torch.int16, device=dev)
+                    _, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64), out=(f32.data_ptr(), n))
+                    self.engine.pcm16_device(f32.data_ptr(), audio.data_ptr(), n)
+                    del f32
+                else:
+                    audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
                 self.stats["s_decode"] += time.perf_counter() - t0
                 self.stats["batches"] += 1
                 self.stats["frames"] += real
@@ -170,21 +187,29 @@ def ordered_gather_pcm16(local: dict, n_total: int, group=None, dst: int = 0, de
     import torch.distributed as dist
     from . import wav
 
+    dev = torch.device("cpu") if device is None else torch.device(device)
+
     def pcm(a):
+        """-> int16 torch tensor on ``dev``.  Device-resident int16 (BatchSynthesizer(output="pcm16_device"): converted
+        by k82_pcm16 on the GPU) passes through untouched; host float32 is converted on the host with the same
+        expression; host int16 is taken as it is."""
+        if torch.is_tensor(a):
+            if a.dtype != torch.int16:
+                raise TypeError("ordered_gather_pcm16: tensors must be int16 (convert on the device with Engine.pcm16_device)")
+            return a.to(dev)
         a = np.asarray(a)
-        return a if a.dtype == np.int16 else wav.f32_to_s16le_array(a)
+        return torch.from_numpy(a if a.dtype == np.int16 else wav.f32_to_s16le_array(a)).to(dev)
 
     idx = sorted(local)
     blocks = [pcm(local[i]) for i in idx]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         if idx != list(range(n_total)):
             raise RuntimeError("ordered_gather_pcm16: a single rank must hold every sentence")
-        return blocks
+        return [b.cpu().numpy() for b in blocks]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     meta = [None] * world
     dist.all_gather_object(meta, (idx, [int(b.shape[0]) for b in blocks]), group=group)
-    dev = torch.device("cpu") if device is None else torch.device(device)
-    mine = torch.from_numpy(np.concatenate(blocks) if blocks else np.zeros((0,), np.int16)).to(dev)
+    mine = torch.cat(blocks) if blocks else torch.zeros((0,), dtype=torch.int16, device=dev)
     if rank != dst:
         if mine.numel():
             dist.send(mine, dst=dst, group=group)
