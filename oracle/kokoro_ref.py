@@ -181,15 +181,19 @@ class ProsodyPredictor(nn.Module):
         self.F0_proj = nn.Conv1d(d_hid // 2, 1, 1, 1, 0)
         self.N_proj = nn.Conv1d(d_hid // 2, 1, 1, 1, 0)
 
-    def F0Ntrain(self, x, s):                           # x [1, 640, F]
+    def F0Ntrain(self, x, s, taps=None):                # x [1, 640, F]
         x, _ = self.shared(x.transpose(-1, -2))
         F0 = x.transpose(-1, -2)
-        for blk in self.F0:
+        for i, blk in enumerate(self.F0):
             F0 = blk(F0, s)
+            if taps is not None:
+                taps[f"f0_blk{i}"] = F0
         F0 = self.F0_proj(F0)
         N = x.transpose(-1, -2)
-        for blk in self.N:
+        for i, blk in enumerate(self.N):
             N = blk(N, s)
+            if taps is not None:
+                taps[f"n_blk{i}"] = N
         N = self.N_proj(N)
         return F0.squeeze(1), N.squeeze(1), x.transpose(-1, -2)
 
@@ -503,7 +507,7 @@ class KModelRef(nn.Module):
         aln = aln.unsqueeze(0)
         s = ref_s[:, 128:]
         en = d.transpose(-1, -2) @ aln
-        F0_pred, N_pred, shared = self.predictor.F0Ntrain(en, s)
+        F0_pred, N_pred, shared = self.predictor.F0Ntrain(en, s, taps)
         if taps is not None:
             taps["F0"] = F0_pred
             taps["N"] = N_pred

@@ -58,7 +58,7 @@ def _run(engine, g, forced_curves):
             out["F0"], out["N"] = engine.debug_get("F0")[0, 0, :2 * F].copy(), engine.debug_get("N")[0, 0, :2 * F].copy()
             out["stages_F"] = {k: engine.debug_get(k)[0] for k in (
                 "en", "shared", "t_en", "asr", "dec_encode", "dec_out", "gen0_noise_conv", "gen0_xsource", "gen0_out",
-                "gen1_xsource", "gen1_out", "conv_post")}
+                "gen1_xsource", "gen1_out", "conv_post", "f0_blk0", "f0_blk1", "f0_blk2", "n_blk0", "n_blk1", "n_blk2")}
     finally:
         for k in ("F0", "N", "har"):
             engine.debug_force(k, None)
@@ -69,13 +69,13 @@ def _run(engine, g, forced_curves):
 
 def _check_durations(g, r, T):
     """Integer durations bit-exact; pre-rounding values no further from the fp64 arbiter than the fp32 oracle is
-    (x2 + a floor of 1e-4: one fp32 ulp of a sum of 50 sigmoids ~ 25 is 2e-6, the LSTM stack amplifies ~50x)."""
+    (x2 + a floor of 1e-5: five fp32 ulps of a sum of 50 sigmoids ~ 25)."""
     assert np.array_equal(r["pred"], g["pred_dur"]), (r["pred"], g["pred_dur"])
     err_e = float(np.abs(r["raw"].astype(np.float64) - g["raw64"]).max())
     err_o = float(np.abs(g["raw32"].astype(np.float64) - g["raw64"]).max())
     margin = float(np.abs((g["raw64"] % 1.0) - 0.5).min())
     print(f"T{T}: raw duration |engine-fp64| {err_e:.2e}, |oracle32-fp64| {err_o:.2e}, min fp64 rounding margin {margin:.2e}")
-    assert err_e <= 2.0 * err_o + 1e-4, (err_e, err_o)
+    assert err_e <= 2.0 * err_o + 1e-5, (err_e, err_o)
     # every token whose fp64 value is further from a rounding boundary than the engine's own error must round alike
     far = np.abs((g["raw64"] % 1.0) - 0.5) > err_e
     want = np.maximum(np.rint(g["raw64"]), 1).astype(np.int64)
@@ -125,7 +125,7 @@ def test_golden_teacher_forced_waveform(engine, T):
 @pytest.mark.parametrize("T", [8, 64, 256, 512])
 def test_golden_free_running_against_fp64_arbiter(engine, T):
     """No teacher forcing.  The engine's F0 / N curves must be as close to the float64 evaluation of the model as the
-    fp32 oracle's own curves are (x2 + 2e-5 of the range), and so must the waveform (SNR against fp64 no more than 3 dB below the fp32
+    fp32 oracle's own curves are (x2 + 2e-6 of the range), and so must the waveform (SNR against fp64 no more than 3 dB below the fp32
     oracle's SNR against fp64): the free-running sample-wise gap between two fp32 implementations is the model's
     conditioning, not an engine error -- the fp32 oracle itself sits 0.15-0.77 max-abs from the fp64 waveform."""
     g = _load(T)
@@ -137,9 +137,11 @@ def test_golden_free_running_against_fp64_arbiter(engine, T):
         e_orc = float(np.abs(g[name + "_32"].astype(np.float64) - ref64).max())
         scale = float(np.abs(ref64).max())
         print(f"T{T}: {name} |engine-fp64| {e_eng:.2e}, |oracle32-fp64| {e_orc:.2e} (max |{name}| {scale:.1f})")
-        # x2 of the oracle's own distance plus a floor of 2e-5 of the curve's range (measured: T8 3.0x / T64 1.0x /
-        # T256 1.6x / T512 0.07x -- at 510 phonemes the fp32 ORACLE is 0.29 Hz from fp64, the engine 0.02 Hz)
-        assert e_eng <= 2.0 * e_orc + 2e-5 * scale, (name, e_eng, e_orc)
+        # x2 of the oracle's own distance plus a floor of 2e-6 of the curve's range (a few fp32 ulps).  Round 2 measured
+        # 1.6-3.0x here and had widened the floor tenfold to pass; the cause was the conv kernel's single sequential
+        # accumulation chain over K (tools/conv_noise.py), fixed by blocked summation on the prosody layers (conv_mfma.hip
+        # KSPLIT): measured since 0.7-1.1x
+        assert e_eng <= 2.0 * e_orc + 2e-6 * scale, (name, e_eng, e_orc)
         assert e_eng <= 5e-4 * max(scale, 1.0), (name, e_eng, scale)          # relative 5e-4 against the arbiter
     st = int(g["audio_stride"])
     a = r["audio"][::st]
@@ -187,3 +189,37 @@ def test_free_running_waveform_meets_the_bar_on_calm_weights():
             assert err <= AUDIO_TOL, (b, err)
     finally:
         eng.close()
+
+
+STAGE_NOISE = ("bert_out", "d_en", "d", "dur_lstm", "t_en", "shared", "f0_blk0", "f0_blk1", "f0_blk2", "n_blk0", "n_blk1", "n_blk2")
+
+
+@pytest.mark.parametrize("T", [8, 64, 256, 512])
+def test_golden_stage_noise_is_the_oracles(engine, T):
+    """Stage by stage through the token-rate and prosody layers (free-running): the engine's rms distance from the
+    committed float64 evaluation, divided by the fp32 oracle's own rms distance from it (tests/golden/synthetic_T*_stages.npz,
+    2048 strided samples per stage).  A kernel that rounds more than torch's CPU kernel would show as a ratio that jumps
+    at its stage -- round 2's build measured 2.1-3.1 from `bert_out` / `t_en` on (the conv kernel's single sequential K
+    chain); with blocked summation (conv_mfma.hip KSPLIT) every stage sits at 0.3-1.3.  Bound: 1.6 at every stage."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    from make_golden import stage_index
+    g = _load(T)
+    st = np.load(os.path.join(GOLD, f"synthetic_T{T}_stages.npz"))
+    r = _run(engine, g, forced_curves=False)
+    got_all = {**r["stages_T"], **r["stages_F"]}
+    worst = 0.0
+    print(f"T{T}: stage, rms |engine-fp64| / max|fp64|, rms |oracle32-fp64| / max|fp64|, ratio")
+    for k in STAGE_NOISE:
+        C, L = (int(v) for v in st[f"{k}_shape"])
+        flat = np.ascontiguousarray(got_all[k][:C, :L]).reshape(-1)
+        e = flat[stage_index(flat.size)].astype(np.float64)
+        r64, r32 = st[f"{k}_64"], st[f"{k}_32"].astype(np.float64)
+        assert e.shape == r64.shape == r32.shape
+        sc = float(st[f"{k}_absmax"])
+        re_, ro = float(np.sqrt(((e - r64) ** 2).mean())) / sc, float(np.sqrt(((r32 - r64) ** 2).mean())) / sc
+        ratio = re_ / max(ro, 1e-12)
+        worst = max(worst, ratio)
+        print(f"  {k:9s} {re_:.3e} {ro:.3e} {ratio:5.2f}")
+        assert re_ <= 1.6 * ro + 2e-8, (k, re_, ro)
+    print(f"T{T}: worst stage ratio {worst:.2f}")

@@ -95,13 +95,55 @@ def make(T, m32, m64):
           f"{os.path.getsize(os.path.join(GOLD, f'synthetic_T{T}.npz')) / 1e6:.2f} MB")
 
 
+STAGE_NOISE = ("bert_out", "d_en", "d", "dur_lstm", "t_en", "shared", "f0_blk0", "f0_blk1", "f0_blk2", "n_blk0", "n_blk1", "n_blk2")
+STAGE_KEEP = 2048            # elements kept per stage (a fixed stride over the flattened [C, L] tensor)
+
+
+def stage_index(n):
+    return np.arange(n)[::max(1, n // STAGE_KEEP)][:STAGE_KEEP]
+
+
+def make_stages(T, m32, m64):
+    """tests/golden/synthetic_T{T}_stages.npz: strided samples of the token-rate and prosody-branch stage tensors, from
+    the fp32 oracle AND its float64 evaluation, on the inputs / decode durations of synthetic_T{T}.npz.  The GPU test
+    compares |engine - fp64| with |oracle32 - fp64| stage by stage (tests/test_gpu_golden.py): an engine kernel that
+    rounds more than torch's CPU kernel shows as a ratio that jumps at its stage."""
+    g = np.load(os.path.join(GOLD, f"synthetic_T{T}.npz"))
+    x, rs = torch.from_numpy(g["ids"])[None], torch.from_numpy(g["ref_s"])[None]
+    dec = torch.from_numpy(g["decode_dur"].astype(np.int64))
+    idx = torch.repeat_interleave(torch.arange(T), dec)
+    out = {}
+    for tag, m, r in (("32", m32, rs), ("64", m64, rs.double())):
+        taps = {}
+        _, d, _ = m.durations(x, r, 1.0, taps)
+        en = d.transpose(-1, -2)[:, :, idx]                       # == d^T @ one-hot alignment
+        with torch.no_grad():
+            _, _, taps["shared"] = m.predictor.F0Ntrain(en, r[:, 128:], taps)
+            taps["t_en"] = m.text_encoder(x)
+        for k in STAGE_NOISE:
+            a = taps[k].detach().numpy()
+            a = a[0].T if k in ("bert_out", "d", "dur_lstm") else a[0]            # -> [C, L]
+            flat = np.ascontiguousarray(a).reshape(-1)
+            out[f"{k}_{tag}"] = flat[stage_index(flat.size)].astype(np.float32 if tag == "32" else np.float64)
+            out[f"{k}_shape"] = np.array(a.shape, np.int64)
+            if tag == "64":
+                out[f"{k}_absmax"] = np.float64(np.abs(a).max())
+    path = os.path.join(GOLD, f"synthetic_T{T}_stages.npz")
+    np.savez_compressed(path, **out)
+    print(f"T{T} stages: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     sds = spec.synthetic_state_dicts(0)
     m32 = R.build(spec.DEFAULT_CONFIG, sds)
-    which = [int(a) for a in sys.argv[1:]] or [14, 8, 64, 256, 512]
+    stages_only = "--stages" in sys.argv[1:]                      # only the *_stages.npz files (needs the main vectors)
+    which = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [14, 8, 64, 256, 512]
     m64 = R.build(spec.DEFAULT_CONFIG, sds, torch.float64) if any(t != 14 for t in which) else None
     for T in which:
         if T == 14:
-            legacy_T14(m32)
+            if not stages_only:
+                legacy_T14(m32)
         else:
-            make(T, m32, m64)
+            if not stages_only:
+                make(T, m32, m64)
+            make_stages(T, m32, m64)

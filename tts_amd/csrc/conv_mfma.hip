@@ -196,13 +196,23 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // of 32 (co) x 128 (t): a wave then loads only ITS 32 weight rows per tap -- with 2 x 2 waves of 64 x 64 the two waves
 // that share rows both fetch them, and the L1 -> register return path (TD 88 % busy in the bf16 mode, 33 % MFMA) is what
 // those launches wait for.
-template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT>
+// KSPLIT (fp32, two-set loop): BLOCKED summation over K.  One accumulator per output element sums its K = cin * taps
+// products as ONE sequential fp32 chain, so its rounding noise grows like sqrt(K): measured against a float64 result
+// (tools/conv_noise.py) the kernel is as accurate as torch's CPU kernels up to K = 256 and 1.9x / 2.9x / 5.2x noisier at
+// K = 768 / 2048 / 3270, because those sum in blocks of a few hundred products.  With KSPLIT the running accumulator is
+// folded into a second one every ConvP::kflush 16-channel tiles (~256 products) and cleared; the output is the sum of
+// the block sums.  The engine asks for it on the token-rate and prosody layers (ALBERT, duration / F0 / N predictors, text
+// encoder: < 3 % of the FLOPs), whose noise reaches the rounded durations and the F0 curve that the harmonic source
+// integrates into a phase.  Costs 16 * HT * HTN more registers and two vector instructions per accumulator and block.
+// The fold points are positions in K, the same for every tile shape: shapes stay bit-identical to each other.
+template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT, bool KSPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : K82_OCC_F32) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int WT = 32 * HT, WTN = 32 * HTN;    // rows and columns of a wave's output tile
     constexpr int BM = WT * WM, BN = WTN * WN, KC = KCT, WP = BN + 68, NW = WM * WN;
     static_assert(KC == 16 || (KC == 32 && HT == 1 && !BF16), "32-channel tiles: small-launch fp32 kernel only");
+    static_assert(!KSPLIT || (PREC == PREC_F32 && TAPS == 0), "blocked summation: the fp32 two-set loop only");
     static_assert(HT == 2 || (HT == 1 && (!BF16 || HTN == 4)), "one MFMA tile row per wave: the fp32 small-launch shape and the 32 x 128 bf16 shapes");
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
@@ -275,13 +285,30 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     };
 
     floatx16 acc[HT][HTN];
+    floatx16 acc2[KSPLIT ? HT : 1][KSPLIT ? HTN : 1];      // KSPLIT: sum of the finished K blocks
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < HT; ++i)
 #pragma unroll
             for (int j = 0; j < HTN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.f;
+                    if constexpr (KSPLIT) acc2[i][j][r] = 0.f;
+                }
+    };
+    auto fold_acc = [&](bool clear) {                      // acc2 += acc ; acc = clear ? 0 : acc2
+        if constexpr (KSPLIT) {
+#pragma unroll
+            for (int i = 0; i < HT; ++i)
+#pragma unroll
+                for (int j = 0; j < HTN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc2[i][j][r] += acc[i][j][r];
+                        acc[i][j][r] = clear ? 0.f : acc2[i][j][r];
+                    }
+        }
     };
 
     // channel (within the ci-tile) that staging slot cc of this wave carries: fp32 w, w+NW, ...; bf16 modes the
@@ -1055,6 +1082,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
         const float bias_l = p.bias[min(cur.m0 + lane, p.cout_p - 1)];   // bias is padded to cout_p; lands during the main loop
         zero_acc();
         TR(1);
+        int kleft = KSPLIT ? p.kflush : 0;                 // 16-channel tiles until the next fold
         int tap = cur.tap0;
         auto next_tap = [&](int t) -> int {
             const unsigned mm = (t >= 31) ? 0u : (cur.mask >> (t + 1));
@@ -1150,6 +1178,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                     }
                 }
             }
+            if constexpr (KSPLIT) {
+                kleft -= KC / 16;
+                if (kleft <= 0 && more) { fold_acc(true); kleft = p.kflush; }      // (wave-uniform)
+            }
             // raw barrier: LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e. wait here for the
             // weight fragments just requested for the next ci-tile.
             TR(5);
@@ -1190,6 +1222,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             }
         }
         TR(6);
+        fold_acc(false);                                   // KSPLIT: the last block joins the others
         epilogue(cur, bias_l);
         TR(7);
         if (!have_next) break;
@@ -1198,6 +1231,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     }
     }
 }
+
+static std::atomic<long> g_shape_launches[CONV_NSHAPE];
+long conv_shape_launches(int shape) { return shape >= 0 && shape < CONV_NSHAPE ? g_shape_launches[shape].load() : -1; }
+static inline unsigned ncu(const ConvP& p) { return p.cus > 0 ? (unsigned)p.cus : 256u; }
 
 template <int WM, int WN, bool SNAKE, int BF16, int HT = 2, int KCT = 16, int TAPS = 0, int HTN = HT>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
@@ -1214,12 +1251,19 @@ static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
 template <int WM, int WN, int HT = 2, int KCT = 16>
 static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
     if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT, KCT>(p, epi, grid, s);
-    else launch_epi<WM, WN, false, PREC_F32, HT, KCT>(p, epi, grid, s);
+    else if (WM >= 2 && p.kflush > 0 && epi != EPI_ACC && p.cin_p > 16 * p.kflush) {
+        // blocked summation (KSPLIT): no Snake conv and no running-mean epilogue asks for it; the 1 x 4 shape (<= 64 output
+        // channels: the duration and F0 / N heads, K <= 512) is not built with it
+        if constexpr (WM >= 2) {
+            ++g_shape_launches[CONV_SHAPE_KSPLIT];
+            switch (epi) {
+            case EPI_PLAIN: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, false, PREC_F32, KCT, 0, HT, true>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
+            case EPI_RES:   hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, false, PREC_F32, KCT, 0, HT, true>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
+            default:        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_SCALAR, false, PREC_F32, KCT, 0, HT, true>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
+            }
+        }
+    } else launch_epi<WM, WN, false, PREC_F32, HT, KCT>(p, epi, grid, s);
 }
-static std::atomic<long> g_shape_launches[CONV_NSHAPE];
-long conv_shape_launches(int shape) { return shape >= 0 && shape < CONV_NSHAPE ? g_shape_launches[shape].load() : -1; }
-static inline unsigned ncu(const ConvP& p) { return p.cus > 0 ? (unsigned)p.cus : 256u; }
-
 template <int PREC>
 static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
@@ -1341,6 +1385,7 @@ void launch_conv(const ConvP& p, hipStream_t s) {
             const unsigned grid = (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks);
             if (p.taps == 1 && (epi == EPI_PLAIN || epi == EPI_RES)) launch_shape<2, 2, 1, 32>(p, epi, grid, s);
             else launch_shape<2, 2, 1>(p, epi, grid, s);
+            ++g_shape_launches[CONV_SHAPE_LDS3];
         }
 #if K82_F32_BM256
         // >= 256 output channels, large launches: 4 x 2 waves on 256 x 128 tiles, one workgroup per CU -- the staged x tile

@@ -242,6 +242,8 @@ struct k82_handle {
     }
     int precision = 0;                 // k82_set_precision: 0 fp32 everywhere, 1 bf16 MFMA in decoder + generator
     bool bf16_now = false;             // true only while decode() is inside the decoder / generator
+    bool bf16_zone = false;            // true while decode() is inside the decoder / generator, whatever the precision mode
+    bool precise = true;               // K82_KSPLIT=0: no blocked summation anywhere (A/B and noise measurements)
     size_t aT_mark_cur = 0, aT_mark_off = 0;
     int B = 0, Tmax = 0, Tp = 0;
     std::vector<int> lens_h, dur_h;
@@ -632,6 +634,7 @@ struct k82_handle {
             lstm_split_max_b = cus / 2;          // 4 sentences per workgroup: one resident round up to CUs / 2 sentences
             if (const char* e = std::getenv("K82_FUSED_STATS")) fused_stats = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_RING")) ring_off = std::atoi(e) == 0;
+            if (const char* e = std::getenv("K82_KSPLIT")) precise = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_BM256")) bm256_off = std::atoi(e) == 0;
             // K82_LSTM_SPLIT_MAX_B=0: streaming kernel everywhere -- for deployments that KNOW the GPU is shared
             if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));
@@ -664,6 +667,9 @@ struct k82_handle {
         p.B = nb; p.Lmax_out = Lmax;
         p.dbg = (ring_off ? 1 : 0) | (bm256_off ? 2 : 0);
         p.cus = cus; p.spin_limit = conv_spin_limit; p.err = conv_err;
+        // blocked summation on every fp32 layer outside the decoder / generator (durations, F0 / N, text encoder): fold every
+        // ~256 products (conv_mfma.hip KSPLIT).  16 / taps 16-channel tiles, kept even for the 32-channel small-launch tiles.
+        p.kflush = (precise && !bf16_zone) ? std::max(2, (16 / std::max(1, w.taps)) & ~1) : 0;
         return p;
     }
     // operand shapes the kernel and its grid assume (conv_mfma.hip launch_conv), checked before every launch
@@ -1004,10 +1010,13 @@ struct k82_handle {
             const ResBlk1dW* blk = which ? nblk : f0blk;
             float* a = aF.f((size_t)nb * H * PF);
             resblk1d(blk[0], sh, (long)H * PF, PF, lF, Fmax, hb, sumF, a, (long)H * PF, PF, gbp, Gp, aF, false);
+            tap(which ? "n_blk0" : "f0_blk0", a, H, PF, (long)H * PF, nb);
             float* bq = aF.f((size_t)nb * (H / 2) * P2);
             resblk1d(blk[1], a, (long)H * PF, PF, lF, Fmax, hb, sumF, bq, (long)(H / 2) * P2, P2, gbp, Gp, aF, false);
+            tap(which ? "n_blk1" : "f0_blk1", bq, H / 2, P2, (long)(H / 2) * P2, nb);
             float* c = aF.f((size_t)nb * (H / 2) * P2);
             resblk1d(blk[2], bq, (long)(H / 2) * P2, P2, l2F, 2 * Fmax, hb, 2 * sumF, c, (long)(H / 2) * P2, P2, gbp, Gp, aF, false);
+            tap(which ? "n_blk2" : "f0_blk2", c, H / 2, P2, (long)(H / 2) * P2, nb);
             run_conv(cp(which ? nproj : f0proj, c, (long)(H / 2) * P2, P2, which ? nn : f0, P2, P2, l2F, l2F, nb, 2 * Fmax), hb);
         }
         apply_forced("F0", f0, P2, 1, 2 * nfr_h[0]);
@@ -1043,8 +1052,9 @@ struct k82_handle {
         // bf16 MFMA mode (k82_set_precision): from here on -- decoder and generator convs -- the 2x2-shaped
         // convs take their bf16 weight image; everything before (durations, F0/N curves, text encoder) and
         // conv_post (1x4 shape) stay on the exact-fp32 instruction.  The guard clears the flag on any exit.
-        struct Bf16Scope { bool& f; ~Bf16Scope() { f = false; } } bf16_scope{bf16_now};
+        struct Bf16Scope { bool& f; bool& z; ~Bf16Scope() { f = false; z = false; } } bf16_scope{bf16_now, bf16_zone};
         bf16_now = precision != 0;
+        bf16_zone = true;
         resblk1d(enc, cat0, c0bs, PF, lF, Fmax, hb, sumF, catA, c1bs, PF, gbd, Gd, aF);
         tap("dec_encode", catA, 1024, PF, c1bs, nb);
         for (float* cat : {catA, catB}) {
@@ -1340,7 +1350,7 @@ int k82_prof_read(k82_handle* h, const char* name, double* ms, int64_t* launches
         double m = 0, w = 0; int64_t n = 0; bool found = false;
         if (std::strcmp(name, "lstm_fallbacks") == 0) { n = h->lstm_fallbacks; found = true; }
         // launches of the large-tile conv families since the process started (bit-identity tests assert that they ran)
-        const char* const shapes[CONV_NSHAPE] = {"conv_shape_bm256", "conv_shape_ring_wn2", "conv_shape_ring", "conv_shape_lds3"};
+        const char* const shapes[CONV_NSHAPE] = {"conv_shape_bm256", "conv_shape_ring_wn2", "conv_shape_ring", "conv_shape_lds3", "conv_shape_ksplit"};
         for (int i = 0; i < CONV_NSHAPE; ++i)
             if (std::strcmp(name, shapes[i]) == 0) { n = conv_shape_launches(i); found = true; }
         // workspace of the largest pass so far / capacity held now, in bytes (sizing of k82_reserve, tests)
