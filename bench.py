@@ -157,7 +157,7 @@ def main():
         # HBM bytes per launch of the dominant kernel family come from the committed rocprofv3 PMC passes of this
         # same command (counters cannot be read from inside the process); see profiles/*_traffic.json.
         traffic, traffic_src = None, None
-        tname = {"fp32": "r02_v6_traffic.json", "bf16x3": "r02_v6_traffic_bf16x3.json"}.get(args.dtype)
+        tname = {"fp32": "r03_traffic.json", "bf16": "r03_traffic_bf16.json"}.get(args.dtype)
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname or "")
         if tname and os.path.exists(tp) and B == 64 and T == 256:
             with open(tp) as fh:

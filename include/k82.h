@@ -84,6 +84,15 @@ typedef struct k82_noise {
 /* replaces: Kokoro.__init__ -> ort.InferenceSession(model_path) (speech7.py:82). */
 int k82_create(const k82_config* cfg, int device, k82_handle** out);
 int k82_destroy(k82_handle* h);
+/* A second execution context on the SAME weights: own stream, own workspace, own phase-1 state; nothing is uploaded
+ * again (the fork reads the parent's device memory).  Calls on parent and fork do not serialise against each other, so
+ * one host thread per handle overlaps one batch's token-rate phase (k82_durations: small launches and a device -> host
+ * sync) with another batch's frame-rate phase (k82_decode) on one GPU; a batch gives the same bits on either handle.
+ * The fork inherits the precision mode; it must be destroyed before its parent (k82_destroy(parent) returns K82_ESTATE
+ * while forks live); a fork cannot be forked.
+ * replaces: the reference's two worker threads on one Kokoro object (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715),
+ * which onnxruntime serves with concurrent sess.run calls on one InferenceSession. */
+int k82_fork(k82_handle* parent, k82_handle** out);
 const char* k82_last_error(const k82_handle* h); /* h may be NULL: last create error */
 
 /* Weight upload.  `name` is "<submodule>.<state-dict key>" with weight-norm already folded
@@ -153,15 +162,18 @@ int k82_set_precision(k82_handle* h, int mode);
 int k82_pcm16(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* stream);
 
 /* k82_pcm16 for callers that cannot allocate.  No counterpart in the reference: it exists for callers that must
- * not reach hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * not reach hipMalloc -- tight serving loops, harnesses that forbid allocation.  (The property is "no allocation", not
+ * "capturable": the call queries its pointers, may copy from pageable memory and synchronises the stream, none of
+ * which is legal on a stream that is being captured into a HIP graph.)
  * Same arguments and result as k82_pcm16 (bit-identical output), but the device staging that k82_pcm16 takes from
  * the handle's workspace arena (which may grow) is a fixed static device array inside libk82.so:
  *   - at most K82_PCM16_STATIC_MAX samples per call, else K82_EINVAL and nothing is written;
  *   - the call performs no hipMalloc / hipFree / arena growth; the array's address is resolved once per device in
  *     k82_create;
  *   - every GPU the library runs on holds its own 24 MiB copy until the process ends; all handles of a process on
- *     one GPU share that GPU's copy: calls are serialised per GPU inside the library, and the array keeps the last
- *     call's contents (each call overwrites exactly the [0, n) prefix it then reads). */
+ *     one GPU share that GPU's copy: calls are serialised per GPU inside the library (a process-wide mutex per GPU,
+ *     held across the call's stream synchronize -- two handles on one GPU convert one after the other), and the array
+ *     keeps the last call's contents (each call overwrites exactly the [0, n) prefix it then reads). */
 #define K82_PCM16_STATIC_MAX (4 * 1024 * 1024)
 int k82_pcm16_static(k82_handle* h, const float* src, int16_t* dst, int64_t n, void* stream);
 

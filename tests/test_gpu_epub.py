@@ -149,3 +149,39 @@ def test_device_side_pcm16_gather_gives_the_host_conversions_bytes(engine):
         assert np.array_equal(host[i][1], dev[i][1])
         assert got[i].dtype == np.int16 and np.array_equal(got[i], want[i]), i
         assert np.array_equal(want[i], wav.f32_to_s16le_array(host[i][0]))
+
+
+def test_two_contexts_overlap_phases_and_keep_every_bit(engine):
+    """BatchSynthesizer(contexts=2): two execution contexts on one set of weights (k82_fork), a host thread each, batches
+    handed out in order -- phase 1 of one batch overlaps phase 2 of another (the reference's
+    two pool threads on one Kokoro object, epubviewer_06_latest_1_nov_2025_theme.py:407,692,715).  Every sentence must
+    carry the bits of the single-context pass, in fp32 and in the bf16 mode, and both contexts must have worked."""
+    sents = [t for _, t in _book("epub_art_of_war.json.gz")["sentences"]][400:560]
+    ids = _ids_of(sents)
+    pack = spec.synthetic_voice_pack(1)
+    rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
+    seeds = [7000 + i for i in range(len(ids))]
+    one = BatchSynthesizer(engine, max_batch=16)
+    two = BatchSynthesizer(engine, max_batch=16, contexts=2)
+    try:
+        assert len(two.engines) == 2 and two.engines[1] is not engine
+        for mode in ("fp32", "bf16"):
+            engine.set_precision(mode)                            # (reaches the fork too)
+            assert two.engines[1].precision == mode
+            try:
+                a = one.synthesize(ids, rows, seeds=seeds)
+                before = [e.prof_read("arena_frame")[1] for e in two.engines]
+                b = two.synthesize(ids, rows, seeds=seeds)
+            finally:
+                engine.set_precision("fp32")
+            assert sorted(a) == sorted(b) == list(range(len(ids)))
+            for i in range(len(ids)):
+                assert np.array_equal(a[i][1], b[i][1]) and np.array_equal(a[i][0], b[i][0]), (mode, i)
+            if mode == "fp32":                                    # the fork started without a workspace: it must have grown one
+                assert before[1] == 0 and two.engines[1].prof_read("arena_frame")[1] > 0
+        assert two.stats["batches"] == one.stats["batches"] >= 16
+        # a parent cannot go while its fork lives
+        assert engine.lib.k82_destroy(engine.h) == -1 and b"k82_fork" in engine.lib.k82_last_error(engine.h)
+    finally:
+        two.close()
+    assert len(two.engines) == 1 and not engine._forks

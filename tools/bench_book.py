@@ -30,6 +30,7 @@ ap.add_argument("--frame-pad-limit", type=float, default=None, help="BatchSynthe
 ap.add_argument("--skip-latency", action="store_true")
 ap.add_argument("--prof", action="store_true", help="per-kernel-family GPU time of the cfg3 pass (HIP events; slows it a little)")
 ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32")
+ap.add_argument("--contexts", type=int, default=1, help="execution contexts on the one set of weights (k82_fork), a host thread each")
 args = ap.parse_args()
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -45,8 +46,8 @@ pack = spec.synthetic_voice_pack(1)
 rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
 
 eng = Engine(spec.synthetic_state_dicts(0), precision=args.dtype)
-syn = BatchSynthesizer(eng, max_batch=args.max_batch, **({} if args.frame_pad_limit is None else {"frame_pad_limit": args.frame_pad_limit}))
-syn.synthesize(ids[:64], rows[:64])                        # warm-up (arena growth, first launches)
+syn = BatchSynthesizer(eng, max_batch=args.max_batch, contexts=args.contexts, **({} if args.frame_pad_limit is None else {"frame_pad_limit": args.frame_pad_limit}))
+syn.synthesize(ids[:64 * args.contexts], rows[:64 * args.contexts])   # warm-up (arena growth, first launches)
 t0 = time.perf_counter()
 syn.stats = {k: 0 for k in syn.stats}
 eng.host_alloc_s = 0.0
@@ -62,10 +63,11 @@ if args.prof:
     eng.prof_enable(False)
 a = audio_seconds([res[i][0] for i in range(len(ids))])
 tok = sum(len(x) + 2 for x in ids)
-print(json.dumps({"config": f"cfg3 (1 GPU, {args.dtype}): The Art of War, every sentence", "sentences": len(ids), "tokens": tok,
+print(json.dumps({"config": f"cfg3 (1 GPU, {args.dtype}, {args.contexts} context(s)): The Art of War, every sentence", "sentences": len(ids), "tokens": tok,
                   "mean_tokens": tok / len(ids), "audio_s": a, "wall_s": dt, "audio_s_per_s": a / dt,
                   "phonemes": "surrogate g2p (no phonemizer offline)", "weights": "seeded random",
                   "includes": "host packing, H2D ids, D2H audio copies per batch", "gpu_seconds_by_family": fam, "scheduler": dict(syn.stats, frame_pad_limit=syn.frame_pad_limit, host_alloc_s=eng.host_alloc_s)}), flush=True)
+syn.close()
 if args.skip_latency:
     eng.close()
     sys.exit(0)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("K82_LIB_PATH") or os.path.join(_HERE, "libk82.so")
 K82_OK, K82_ENOSPC = 0, -28
 
 EXPORTS = (
-    "k82_create", "k82_destroy", "k82_last_error", "k82_set_tensor", "k82_finalize", "k82_durations",
+    "k82_create", "k82_fork", "k82_destroy", "k82_last_error", "k82_set_tensor", "k82_finalize", "k82_durations",
     "k82_decode", "k82_synthesize", "k82_reserve", "k82_pcm16", "k82_pcm16_static", "k82_set_precision", "k82_prof_enable", "k82_prof_read", "k82_debug_enable",
     "k82_debug_info", "k82_debug_copy", "k82_debug_force", "k82_op_conv1d",
 )

@@ -68,6 +68,9 @@
 #ifndef K82_RING_BM256
 #define K82_RING_BM256 1            // bf16 ring, >= 256 output channels, large launches: 256 x 128 tiles, 8 x 1 waves (+1.5 % on configs[1])
 #endif
+#ifndef K82_N32_HTN
+#define K82_N32_HTN 2               // MFMA tiles along t per wave in the 32-row fp32 shape (conv_post, the F0 / N heads): 2 = 256-column workgroup tiles
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -323,12 +326,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     const int nstride = (p.tr == TR_NORM) ? p.nstride : 0, nclamp = (p.tr == TR_NORM) ? p.cin - 1 : 0;
     const float4 nid = make_float4(0.f, p.tr == TR_SCALE ? p.in_scale : 1.f, 1.f, 0.f);
     const float slope = (p.act == ACT_LEAKY) ? p.slope : 1.f;
+    const int wlast = (BN + (p.taps - 1) * p.dil + 2) & ~3;     // offset of the last float4 of an x tile that any tap reads
     // raw global loads of one ci-tile (no transform yet): wave w takes channels w, w+NW, ...
     // All loads are UNCONDITIONAL with clamped (always in-bounds) coordinates; validity is applied
     // later with selects.
     auto load_tile = [&](const Tile& T, int ci0, bool params = true) {      // params: a constant at every call site
         const float* xb = p.x + (long)T.b * p.xbs;
-        const int tlast = ((T.Lin - 1) >> 2) << 2;          // last aligned float4 that starts inside the row
+        // last aligned float4 that starts inside the row AND inside the columns the taps read (BN + halo + shift <= 3):
+        // a 64-lane sweep covers 256 columns, a 128-column tile needs 131-181 of them -- the lanes beyond re-read the
+        // tile's last float4 (same cache line as their neighbour's) instead of pulling the next tile's columns through
+        // L2 and HBM (round 2 measured 2.2x the algorithmic read traffic on the Snake convs, profiles/r02_v6_traffic.json)
+        const int tlast = min(((T.Lin - 1) >> 2) << 2, T.tbase + wlast);
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const int ci = min(ci0 + chan(cc), p.cin - 1);
@@ -525,12 +533,11 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     };
     // fp32: B fragments (k-step kk: rows 2 kk + lhi of the tile) as single ds_read_b32 with immediate offsets; the
     // compiler fences keep the load merger from pairing them into ds_read2_b32 (see mfma_tap)
-    float bpf[2] = {0.f, 0.f};
-    auto read_b32 = [&](const float* xsp, int kk, float (&d)[2]) {
-        d[0] = xsp[2 * kk * WP];
-        asm volatile("" ::: "memory");
-        if constexpr (HT == 2) {
-            d[1] = xsp[2 * kk * WP + 32];
+    float bpf[HTN] = {};
+    auto read_b32 = [&](const float* xsp, int kk, float (&d)[HTN]) {
+#pragma unroll
+        for (int ni = 0; ni < HTN; ++ni) {
+            d[ni] = xsp[2 * kk * WP + 32 * ni];
             asm volatile("" ::: "memory");
         }
     };
@@ -573,20 +580,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             // offsets need a v_add_u32 per k-step), wait for it, four MFMAs, next pair.
             const float* xsp = xsb + lhi * WP + nw + l31 + off;
             const float* xnp = xsb + lhi * WP + nw + l31 + offn;
-            float bb[KC / 2][2];
-            bb[0][0] = bpf[0]; bb[0][1] = bpf[1];
+            float bb[KC / 2][HTN];
+#pragma unroll
+            for (int ni = 0; ni < HTN; ++ni) bb[0][ni] = bpf[ni];
 #pragma unroll
             for (int kk = 1; kk < KC / 2; ++kk) read_b32(xsp, kk, bb[kk]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
                 if (kk == KC / 2 - 2) read_b32(xnp, 0, bpf);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], bb[kk][0], acc[0][0], 0, 0, 0);
-                if constexpr (HT == 2) {
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][0], bb[kk][1], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], bb[kk][0], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][1], bb[kk][1], acc[1][1], 0, 0, 0);
-                }
+#pragma unroll
+                for (int mi = 0; mi < HT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < HTN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[kk][mi], bb[kk][ni], acc[mi][ni], 0, 0, 0);
             }
         }
     };
@@ -1232,6 +1239,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     }
 }
 
+#define REQUIRE_SNAKE_FREE(p) do { if ((p).act == ACT_SNAKE) { fprintf(stderr, "k82: Snake conv with <= 32 output channels is not built\n"); return; } } while (0)
 static std::atomic<long> g_shape_launches[CONV_NSHAPE];
 long conv_shape_launches(int shape) { return shape >= 0 && shape < CONV_NSHAPE ? g_shape_launches[shape].load() : -1; }
 static inline unsigned ncu(const ConvP& p) { return p.cus > 0 ? (unsigned)p.cus : 256u; }
@@ -1248,8 +1256,12 @@ static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
         break;
     }
 }
-template <int WM, int WN, int HT = 2, int KCT = 16>
+template <int WM, int WN, int HT = 2, int KCT = 16, int HTN = HT>
 static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
+    if constexpr (HTN != HT) {          // the 32-row shape: no Snake conv has <= 32 output channels
+        launch_epi<WM, WN, false, PREC_F32, HT, KCT, 0, HTN>(p, epi, grid, s);
+        return;
+    }
     if (p.act == ACT_SNAKE) launch_epi<WM, WN, true, PREC_F32, HT, KCT>(p, epi, grid, s);
     else if (WM >= 2 && p.kflush > 0 && epi != EPI_ACC && p.cin_p > 16 * p.kflush) {
         // blocked summation (KSPLIT): no Snake conv and no running-mean epilogue asks for it; the 1 x 4 shape (<= 64 output
@@ -1396,6 +1408,14 @@ void launch_conv(const ConvP& p, hipStream_t s) {
         }
 #endif
         else { launch_shape<2, 2>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s); ++g_shape_launches[CONV_SHAPE_LDS3]; }
+    } else if (p.cout_p == 32) {
+        // <= 32 output channels (conv_post: 22; the F0 / N heads: 1): 1 x 4 waves of 32 x (32 K82_N32_HTN) -- half the MFMAs
+        // of the 64-row shape for the same staged x tile (22 useful rows of 32 instead of 22 of 64)
+        constexpr int BN32 = 4 * 32 * K82_N32_HTN;
+        const long total = (long)((p.Lmax_out + BN32 - 1) / BN32) * p.B;
+        const long cap = (long)cus * (K82_N32_HTN > 2 ? 1 : K82_OCC_F32);
+        REQUIRE_SNAKE_FREE(p);
+        launch_shape<1, 4, 1, 16, K82_N32_HTN>(p, epi, (unsigned)(total < cap ? total : cap), s);
     } else {
         const long total = (long)((p.Lmax_out + 255) / 256) * (p.cout_p / 64) * p.B;
         launch_shape<1, 4>(p, epi, (unsigned)(total < kMaxBlocks ? total : kMaxBlocks), s);

@@ -6,6 +6,7 @@
 #include "../../include/k82.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -179,18 +180,10 @@ struct DebugT { std::vector<float> v; int64_t dims[3]; };
 
 }  // namespace
 
-struct k82_handle {
-    k82_config cfg{};
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t st = nullptr;          // stream of the current call
-    std::mutex mu;
-    std::string err;
-    bool finalized = false;
-    std::unordered_map<std::string, HostT> host;
-    std::vector<void*> wallocs;        // device weight allocations
-
-    // ---- weights
+namespace {
+// Everything finalize() builds from the checkpoint: device pointers and shapes only (trivially copyable).  A handle made by
+// k82_fork takes a copy of this block -- the same device memory, owned by the handle that uploaded it.
+struct K82Weights {
     float *w_word, *w_pos, *w_type0; LNW ln_emb, ln_attn, ln_full;
     ConvW map_in, qkv, attn_dense, ffn, ffn_out, bert_enc;
     LstmW dlstm[3], plstm, shared, telstm;
@@ -202,6 +195,21 @@ struct k82_handle {
     float *lin_w, *lin_b; ConvW nconv0, nconv1, ups0, ups1, conv_post;
     ResBlock1W nres[2], rb[6];
     float *sfc_pros_w, *sfc_pros_b, *sfc_dec_w, *sfc_dec_b; int Gp = 0, Gd = 0;
+};
+}  // namespace
+
+struct k82_handle : K82Weights {
+    k82_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t st = nullptr;          // stream of the current call
+    std::mutex mu;
+    std::string err;
+    bool finalized = false;
+    std::unordered_map<std::string, HostT> host;
+    std::vector<void*> wallocs;        // device weight allocations
+    k82_handle* parent = nullptr;      // k82_fork: the handle whose weights this one reads (it must outlive this one)
+    std::atomic<int> forks{0};         // live handles forked from this one
 
     unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (k82_pcm16_static)
 
@@ -246,6 +254,8 @@ struct k82_handle {
     bool precise = true;               // K82_KSPLIT=0: no blocked summation anywhere (A/B and noise measurements)
     size_t aT_mark_cur = 0, aT_mark_off = 0;
     int B = 0, Tmax = 0, Tp = 0;
+    int Ptot = 0, Pp = 0;              // phase 1 runs in the PACKED token layout (kernels.h LenSpec::off): sum of lens, row pitch
+    std::vector<int> toff_h; int* toff_d = nullptr;    // column offset of every sentence on the packed axis
     std::vector<int> lens_h, dur_h;
     int64_t* ids_d = nullptr; int* lens_d = nullptr; float* refs_d = nullptr; float* speed_d = nullptr;
     float *gbp = nullptr, *gbd = nullptr, *dcat = nullptr; int* dur_d = nullptr; float* raw_d = nullptr;
@@ -397,13 +407,25 @@ struct k82_handle {
             HIPCHK(hipMemcpy(d.v.data() + (size_t)b * C * pitch, p + (long)b * bs, (size_t)C * pitch * sizeof(float), hipMemcpyDeviceToHost));
     }
 
+    // a PACKED token-rate tensor [C][Pp], handed to the tests in the padded form {B, C, Tp} they know
+    void tap_packed(const char* name, const float* p, int C) {
+        if (!debug_on) return;
+        HIPCHK(hipStreamSynchronize(st));
+        DebugT& d = dbg[name];
+        d.dims[0] = B; d.dims[1] = C; d.dims[2] = Tp;
+        d.v.assign((size_t)B * C * Tp, 0.f);
+        for (int b = 0; b < B; ++b)
+            HIPCHK(hipMemcpy2D(d.v.data() + (size_t)b * C * Tp, (size_t)Tp * sizeof(float), p + toff_h[b], (size_t)Pp * sizeof(float),
+                               (size_t)lens_h[b] * sizeof(float), C, hipMemcpyDeviceToHost));
+    }
+
     // ------------------------------------------------------------------ weight builders
     // W host [cout][cin][k] -> device [k][cin_p][cout_p]
     ConvW mk_conv_raw(const std::vector<float>& W, const std::vector<float>* bias, int cout, int cin, int k) {
         ConvW c;
         c.cin = cin; c.cout = cout; c.taps = k; c.pad = (k - 1) / 2;
         c.cin_p = ru(cin, 16);
-        c.cout_p = cout <= 64 ? 64 : ru(cout, 128);
+        c.cout_p = cout <= 32 ? 32 : cout <= 64 ? 64 : ru(cout, 128);       // 32: conv_post and the F0 / N heads (the 32-row kernel shape)
         std::vector<float> t((size_t)k * c.cin_p * c.cout_p, 0.f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
@@ -677,11 +699,12 @@ struct k82_handle {
         REQUIRE((p.taps - 1) * p.dil <= 64, K82_EINVAL, "conv halo exceeds the LDS tile");
         REQUIRE(p.x && p.w && p.bias && (p.y || p.accbuf), K82_EINVAL, "conv operand missing");
         REQUIRE(p.cout_p % 128 != 0 || p.wf, K82_EINVAL, "conv fragment image missing");
-        REQUIRE(p.cin_p % 16 == 0 && p.cout_p % 64 == 0 && p.cin <= p.cin_p && p.cout <= p.cout_p, K82_EINVAL, "conv channel padding");
+        REQUIRE(p.cin_p % 16 == 0 && p.cout_p % 32 == 0 && p.cin <= p.cin_p && p.cout <= p.cout_p, K82_EINVAL, "conv channel padding");
         REQUIRE(p.xpitch % 4 == 0 && (!p.y || p.ypitch % 4 == 0) && (!p.res || p.res_shift || p.up_s || p.rpitch % 4 == 0) &&
                 (!p.accbuf || p.apitch % 4 == 0), K82_EINVAL, "conv row pitch must be a multiple of 4 floats");
         REQUIRE(!p.accbuf || (p.res && !p.up_s && !p.res_shift), K82_EINVAL, "accumulating epilogue needs a residual and a plain layout");
         REQUIRE(p.act != ACT_SNAKE || (p.alpha && p.inv_alpha), K82_EINVAL, "snake needs alpha");
+        REQUIRE(p.act != ACT_SNAKE || p.cout_p >= 64, K82_EINVAL, "no Snake conv with <= 32 output channels is built");
         REQUIRE(p.act != ACT_LEAKY || (p.slope >= 0.f && p.slope <= 1.f), K82_EINVAL, "LeakyReLU slope must be in [0, 1]");
         REQUIRE(p.tr != TR_NORM || p.norm, K82_EINVAL, "norm transform needs statistics");
         REQUIRE(!p.stat || (p.y && !p.up_s && !p.res_shift && p.snt * 32 >= p.Lmax_out), K82_EINVAL, "statistics partials need a stored, plain-layout output");
@@ -816,6 +839,20 @@ struct k82_handle {
         }
     }
 
+    // the same on the packed token axis: the input projection sees ONE long row (dense tiles), the recurrences their own columns
+    void lstm_packed(const LstmW& L, const float* x, LenSpec lt, float* y, Arena& ar, double steps) {
+        float* gx = ar.f((size_t)2048 * Pp);
+        const LenSpec lp{nullptr, 0, Ptot, nullptr};
+        run_conv(cp(L.ih, x, 0, Pp, gx, 0, Pp, lp, lp, 1, Ptot), nullptr);
+        if (use_split(B)) {
+            float* hx = ar.f((size_t)ru(B, 4) * 2048);
+            split_used = true;
+            timed(FAM_LSTM, steps, [&] { launch_lstm_split(gx, 0, Pp, L.whh, y, 0, Pp, lt, B, hx, lstm_err, cus, lstm_spin_limit, st); });
+        } else {
+            timed(FAM_LSTM, steps, [&] { launch_lstm(gx, 0, Pp, L.whh, y, 0, Pp, lt, B, st); });
+        }
+    }
+
     // ------------------------------------------------------------------ phase 1
     template <class T> T* to_device(const T* src, size_t n, Arena& ar) {
         T* d = (T*)ar.alloc(n * sizeof(T));
@@ -860,16 +897,22 @@ struct k82_handle {
         aT.reset();
         B = nb; Tmax = tmax; Tp = ru(tmax, 32);
         lens_h.assign(lens, lens + nb);
-        const int Tp_ = Tp;
+        // packed token axis (kernels.h LenSpec::off): sentence b owns the columns [toff[b], toff[b] + lens[b])
+        toff_h.resize(nb);
+        long ptot = 0;
+        for (int b = 0; b < nb; ++b) { toff_h[b] = (int)ptot; ptot += lens[b]; }
+        REQUIRE(ptot <= 400000, K82_EINVAL, "more than 400000 tokens in one batch: split it (32-bit row offsets in the conv epilogue)");
+        Ptot = (int)ptot; Pp = ru(Ptot, 32);
+        const int P = Pp;
         ids_d = to_device(ids, (size_t)nb * tmax, aT);
         lens_d = to_device(lens_h.data(), (size_t)nb, aT);
+        toff_d = to_device(toff_h.data(), (size_t)nb, aT);
         refs_d = to_device(ref_s, (size_t)nb * K82_STYLE_DIM, aT);
         speed_d = to_device(sp.data(), (size_t)nb, aT);
-        HIPCHK(hipStreamSynchronize(st));   // sp / lens_h are stack/host temporaries
-        const LenSpec lt{lens_d, 1, 0};
-        const int* hb = lens_h.data();
-        double sumT = 0;
-        for (int b = 0; b < nb; ++b) sumT += lens[b];
+        HIPCHK(hipStreamSynchronize(st));   // sp is a stack temporary
+        const LenSpec lt{lens_d, 1, 0, toff_d};              // the per-sentence kernels: own columns of the packed axis
+        const LenSpec lp{nullptr, 0, Ptot, nullptr};         // the Linears (1-tap convs): the batch is one long row
+        const double sumT = (double)Ptot;
         const int D = cfg.bert_hidden, I = cfg.bert_inter;
 
         gbp = aT.f((size_t)nb * Gp);
@@ -878,57 +921,56 @@ struct k82_handle {
         timed(FAM_OTHER, 0, [&] { launch_style_fc(sfc_dec_w, sfc_dec_b, Gd, refs_d, 0, gbd, Gd, nb, st); });
 
         // ---- ALBERT
-        float* emb = aT.f((size_t)nb * 128 * Tp_);
-        timed(FAM_OTHER, 0, [&] { launch_albert_embed(ids_d, tmax, w_word, w_pos, w_type0, ln_emb.w, ln_emb.b, 1e-12f, emb, (long)128 * Tp_, Tp_, lt, nb, cfg.n_token, st); });
-        const long hbs = (long)D * Tp_;
-        float* h = aT.f((size_t)nb * D * Tp_);
-        float* h1 = aT.f((size_t)nb * D * Tp_);
-        float* tmp = aT.f((size_t)nb * D * Tp_);
-        float* ctx = aT.f((size_t)nb * D * Tp_);
-        float* qkvb = aT.f((size_t)nb * 3 * D * Tp_);
-        float* ff = aT.f((size_t)nb * I * Tp_);
-        run_conv(cp(map_in, emb, (long)128 * Tp_, Tp_, h, hbs, Tp_, lt, lt, nb, tmax), hb);
+        float* emb = aT.f((size_t)128 * P);
+        timed(FAM_OTHER, 0, [&] { launch_albert_embed(ids_d, tmax, w_word, w_pos, w_type0, ln_emb.w, ln_emb.b, 1e-12f, emb, 0, P, lt, nb, cfg.n_token, st); });
+        float* h = aT.f((size_t)D * P);
+        float* h1 = aT.f((size_t)D * P);
+        float* tmp = aT.f((size_t)D * P);
+        float* ctx = aT.f((size_t)D * P);
+        float* qkvb = aT.f((size_t)3 * D * P);
+        float* ff = aT.f((size_t)I * P);
+        auto lin = [&](const ConvW& w, const float* x, float* y) { return cp(w, x, 0, P, y, 0, P, lp, lp, 1, Ptot); };
+        run_conv(lin(map_in, emb, h), nullptr);
         for (int layer = 0; layer < cfg.bert_layers; ++layer) {
-            run_conv(cp(qkv, h, hbs, Tp_, qkvb, 3 * hbs, Tp_, lt, lt, nb, tmax), hb);
+            run_conv(lin(qkv, h, qkvb), nullptr);
             double aw = 0;
             for (int b = 0; b < nb; ++b) aw += 4.0 * D * (double)lens[b] * lens[b];
-            timed(FAM_ATTN, aw, [&] { launch_attention(qkvb, 3 * hbs, Tp_, ctx, hbs, Tp_, lt, cfg.bert_heads, nb, tmax, st); });
-            ConvP pd = cp(attn_dense, ctx, hbs, Tp_, tmp, hbs, Tp_, lt, lt, nb, tmax);
-            pd.res = h; pd.rbs = hbs; pd.rpitch = Tp_;
-            run_conv(pd, hb);
-            timed(FAM_OTHER, 0, [&] { launch_layernorm_cols(tmp, nullptr, h1, hbs, hbs, Tp_, lt, D, nb, tmax, 1e-12f, ln_attn.w, ln_attn.b, nullptr, 0, 0, 1.0f, st); });
-            ConvP pf = cp(ffn, h1, hbs, Tp_, ff, (long)I * Tp_, Tp_, lt, lt, nb, tmax);
+            timed(FAM_ATTN, aw, [&] { launch_attention(qkvb, 0, P, ctx, 0, P, lt, cfg.bert_heads, nb, tmax, st); });
+            ConvP pd = lin(attn_dense, ctx, tmp);
+            pd.res = h; pd.rbs = 0; pd.rpitch = P;
+            run_conv(pd, nullptr);
+            timed(FAM_OTHER, 0, [&] { launch_layernorm_cols(tmp, nullptr, h1, 0, 0, P, lt, D, nb, tmax, 1e-12f, ln_attn.w, ln_attn.b, nullptr, 0, 0, 1.0f, st); });
+            ConvP pf = lin(ffn, h1, ff);
             pf.out_act = OACT_GELU_NEW;
-            run_conv(pf, hb);
-            ConvP po = cp(ffn_out, ff, (long)I * Tp_, Tp_, tmp, hbs, Tp_, lt, lt, nb, tmax);
-            po.res = h1; po.rbs = hbs; po.rpitch = Tp_;
-            run_conv(po, hb);
-            timed(FAM_OTHER, 0, [&] { launch_layernorm_cols(tmp, nullptr, h, hbs, hbs, Tp_, lt, D, nb, tmax, 1e-12f, ln_full.w, ln_full.b, nullptr, 0, 0, 1.0f, st); });
+            run_conv(pf, nullptr);
+            ConvP po = lin(ffn_out, ff, tmp);
+            po.res = h1; po.rbs = 0; po.rpitch = P;
+            run_conv(po, nullptr);
+            timed(FAM_OTHER, 0, [&] { launch_layernorm_cols(tmp, nullptr, h, 0, 0, P, lt, D, nb, tmax, 1e-12f, ln_full.w, ln_full.b, nullptr, 0, 0, 1.0f, st); });
         }
-        tap("bert_out", h, D, Tp_, hbs, nb);
+        tap_packed("bert_out", h, D);
 
         // ---- bert_encoder + DurationEncoder (rows a6, a7)
         const int H = cfg.hidden_dim;
-        const long dbs = (long)640 * Tp_;
-        dcat = aT.f((size_t)nb * 640 * Tp_);
-        run_conv(cp(bert_enc, h, hbs, Tp_, dcat, dbs, Tp_, lt, lt, nb, tmax), hb);
-        tap("d_en", dcat, H, Tp_, dbs, nb);
-        timed(FAM_OTHER, 0, [&] { launch_fill_rows(dcat, dbs, Tp_, H, 128, refs_d, K82_STYLE_DIM, 128, lt, nb, tmax, st); });
-        float* hl = aT.f((size_t)nb * H * Tp_);
+        dcat = aT.f((size_t)640 * P);
+        run_conv(lin(bert_enc, h, dcat), nullptr);
+        tap_packed("d_en", dcat, H);
+        timed(FAM_OTHER, 0, [&] { launch_fill_rows(dcat, 0, P, H, 128, refs_d, K82_STYLE_DIM, 128, lt, nb, tmax, st); });
+        float* hl = aT.f((size_t)H * P);
         for (int l = 0; l < 3; ++l) {
-            lstm(dlstm[l], dcat, dbs, Tp_, 640, lt, tmax, hb, hl, (long)H * Tp_, Tp_, aT, sumT);
+            lstm_packed(dlstm[l], dcat, lt, hl, aT, sumT);
             // AdaLayerNorm writes rows 0..511 of dcat; the style rows 512..639 stay
-            timed(FAM_OTHER, 0, [&] { launch_layernorm_cols(hl, nullptr, dcat, (long)H * Tp_, dbs, Tp_, lt, H, nb, tmax, 1e-5f, nullptr, nullptr, gbp, Gp, adaln_off[l], 1.0f, st); });
+            timed(FAM_OTHER, 0, [&] { launch_layernorm_cols(hl, nullptr, dcat, 0, 0, P, lt, H, nb, tmax, 1e-5f, nullptr, nullptr, gbp, Gp, adaln_off[l], 1.0f, st); });
         }
-        tap("d", dcat, 640, Tp_, dbs, nb);
+        tap_packed("d", dcat, 640);
         // ---- duration head (row a8)
-        lstm(plstm, dcat, dbs, Tp_, 640, lt, tmax, hb, hl, (long)H * Tp_, Tp_, aT, sumT);
-        tap("dur_lstm", hl, H, Tp_, (long)H * Tp_, nb);
-        float* logits = aT.f((size_t)nb * cfg.max_dur * Tp_);
-        run_conv(cp(dur_proj, hl, (long)H * Tp_, Tp_, logits, (long)cfg.max_dur * Tp_, Tp_, lt, lt, nb, tmax), hb);
+        lstm_packed(plstm, dcat, lt, hl, aT, sumT);
+        tap_packed("dur_lstm", hl, H);
+        float* logits = aT.f((size_t)cfg.max_dur * P);
+        run_conv(lin(dur_proj, hl, logits), nullptr);
         dur_d = (int*)aT.alloc((size_t)nb * tmax * sizeof(int));
         raw_d = aT.f((size_t)nb * tmax);
-        timed(FAM_OTHER, 0, [&] { launch_durations(logits, (long)cfg.max_dur * Tp_, Tp_, cfg.max_dur, speed_d, lens_d, nb, tmax, dur_d, raw_d, st); });
+        timed(FAM_OTHER, 0, [&] { launch_durations(logits, 0, P, cfg.max_dur, speed_d, lens_d, nb, tmax, dur_d, raw_d, st, toff_d); });
         tap("duration", raw_d, 1, tmax, tmax, nb);
         dur_h.resize((size_t)nb * tmax);
         if (forced) {
@@ -999,7 +1041,7 @@ struct k82_handle {
         double sumTok = 0;
         for (int b = 0; b < nb; ++b) sumTok += lens_h[b];
         // length regulation: algorithmic bytes = one read of the token rows + one write of the frame rows
-        timed(FAM_GATHER, 4.0 * 640 * (sumTok + sumF), [&] { launch_gather(dcat, (long)640 * Tp_, Tp_, 640, idx, PF, nfr_d, en, (long)640 * PF, PF, nb, Fmax, st); });
+        timed(FAM_GATHER, 4.0 * 640 * (sumTok + sumF), [&] { launch_gather(dcat, 0, Pp, 640, idx, PF, nfr_d, en, (long)640 * PF, PF, nb, Fmax, st, toff_d); });   // (dcat: packed token axis)
         tap("en", en, 640, PF, (long)640 * PF, nb);
         float* sh = aF.f((size_t)nb * H * PF);
         lstm(shared, en, (long)640 * PF, PF, 640, lF, Fmax, hb, sh, (long)H * PF, PF, aF, sumF);
@@ -1235,10 +1277,59 @@ int k82_create(const k82_config* cfg, int device, k82_handle** out) {
     }
 }
 
+// A second execution context on the weights of `parent`: own stream, own workspace arenas, own phase-1 state, own error
+// words -- nothing is uploaded again.  Calls on the two handles do not serialise against each other, so a host thread per
+// handle overlaps one batch's token-rate phase (small, latency-bound launches and its device -> host sync) with another
+// batch's frame-rate phase on the same GPU.  Same kernels, same launch rules: a batch gives the same bits on either handle.
+int k82_fork(k82_handle* parent, k82_handle** out) {
+    if (!parent || !out) { g_create_error = "parent and out must not be NULL"; return K82_EINVAL; }
+    k82_handle* h = nullptr;
+    std::lock_guard<std::mutex> lk(parent->mu);
+    try {
+        REQUIRE(parent->finalized, K82_ESTATE, "k82_fork needs a finalized handle");
+        REQUIRE(!parent->parent, K82_ESTATE, "k82_fork: fork the handle that owns the weights, not one of its forks");
+        h = new k82_handle();
+        h->cfg = parent->cfg;
+        h->device = parent->device;
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        static_cast<K82Weights&>(*h) = static_cast<const K82Weights&>(*parent);
+        h->scratch = parent->scratch;
+        h->cus = parent->cus;
+        h->ring_off = parent->ring_off; h->bm256_off = parent->bm256_off; h->fused_stats = parent->fused_stats; h->precise = parent->precise;
+        h->lstm_split_max_b = parent->lstm_split_max_b; h->lstm_spin_limit = parent->lstm_spin_limit; h->conv_spin_limit = parent->conv_spin_limit;
+        h->precision = parent->precision;
+        h->lstm_err = (int*)h->wmalloc(2 * sizeof(int));        // (wallocs of a fork hold only its own words)
+        h->conv_err = h->lstm_err + 1;
+        HIPCHK(hipMemset(h->lstm_err, 0, 2 * sizeof(int)));
+        h->finalized = true;
+        h->parent = parent;
+        parent->forks.fetch_add(1);
+        *out = h;
+        return K82_OK;
+    } catch (const K82Error& e) {
+        g_create_error = e.what();
+        parent->err = e.what();
+        if (h) { for (void* p : h->wallocs) (void)hipFree(p); if (h->own_stream) (void)hipStreamDestroy(h->own_stream); }
+        delete h;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        delete h;
+        return K82_ENOMEM;
+    }
+}
+
 int k82_destroy(k82_handle* h) {
     if (!h) return K82_EINVAL;
+    if (h->forks.load() > 0) {           // its forks read this handle's weights
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->err = "k82_destroy: " + std::to_string(h->forks.load()) + " handle(s) made by k82_fork are still alive; destroy them first";
+        return K82_ESTATE;
+    }
     {
         std::lock_guard<std::mutex> lk(h->mu);
+        if (h->parent) h->parent->forks.fetch_sub(1);
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
         for (void* p : h->wallocs) (void)hipFree(p);

@@ -14,6 +14,14 @@ struct LenSpec {            // per-sentence valid length
     const int* lens;        // device i32[B]; nullptr => every sentence has length ladd
     int lmul, ladd;
     __host__ __device__ int len(int b) const { return lens ? lmul * lens[b] + ladd : ladd; }
+    // PACKED layout (phase 1, token rate): the sentences of a batch lie side by side on ONE time axis, x[c][off[b] + t]
+    // with off[b] = T_0 + ... + T_{b-1} (device i32[B]) and a row pitch of the whole batch -- every Linear of phase 1 is a
+    // 1-tap conv, for which the batch then is one long sentence (dense 128-column tiles whatever the sentence lengths:
+    // a tile of a 35-token sentence alone is 3/4 padding and re-reads the whole weight matrix for it).  nullptr: the
+    // padded layout, one row block of bs floats per sentence.  Kernels that work per sentence (embedding, attention,
+    // layer norm, BiLSTM, durations, length regulation) take their base offset from base().
+    const int* off;
+    __host__ __device__ long base(int b, long bs) const { return off ? (long)off[b] : (long)b * bs; }
 };
 
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SNAKE = 2 };
@@ -116,11 +124,11 @@ void launch_lstm_split(const float* gx, long gbs, int gpitch, const float* whh, 
 void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
                       LenSpec ls, int B, int Tmax, hipStream_t s);
 void launch_durations(const float* logits, long lbs, int lpitch, int ndur, const float* speed,
-                      const int* lens, int B, int Tmax, int* dur, float* raw, hipStream_t s);
+                      const int* lens, int B, int Tmax, int* dur, float* raw, hipStream_t s, const int* loff = nullptr);   // loff: packed logits
 // idx[b][f] = token index of frame f ; nfr[b] = sum dur
 void launch_alignment(const int* dur, int Tmax, const int* lens, int B, int* idx, int ipitch, int* nfr, hipStream_t s);
 void launch_gather(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch, const int* nfr,
-                   float* y, long ybs, int ypitch, int B, int Fmax, hipStream_t s);
+                   float* y, long ybs, int ypitch, int B, int Fmax, hipStream_t s, const int* xoff = nullptr);        // xoff: packed token rows
 // depthwise ConvTranspose1d k3 s2 p1 op1 over act(norm(x)) : [C][L] -> [C][2L]
 void launch_pool_up2(const float* x, long xbs, int xpitch, const float4* norm, int nstride, float slope,
                      const float* w, const float* bias, float* y, long ybs, int ypitch, LenSpec ls,

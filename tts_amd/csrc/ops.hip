@@ -140,8 +140,8 @@ __global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, co
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < L;
     const int tc = ok ? t : 0;                               // clamped: every lane loads, only valid lanes store
-    const float* xc = x + (long)b * bs + tc;
-    const float* rc = res ? res + (long)b * bs + tc : xc;
+    const float* xc = x + ls.base(b, bs) + tc;
+    const float* rc = res ? res + ls.base(b, bs) + tc : xc;
     const float rmul = res ? 1.f : 0.f;
     float v[LN_MAXCH];
     float s = 0.f;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, co
 #pragma unroll
     for (int k = 0; k < 16; ++k) qt += red[1][k][lane];
     const float rstd = 1.0f / sqrtf(qt / C + eps);
-    float* yc = y + (long)b * ybs + tc;
+    float* yc = y + ls.base(b, ybs) + tc;
     const float* g = gb ? gb + (long)b * gbstride + goff : nullptr;
 #pragma unroll
     for (int i = 0; i < LN_MAXCH; ++i) {
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64) void layernorm_cols_serial_kernel(const float* 
                                                                   int gbstride, int goff, float leaky) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
     if (t >= ls.len(b)) return;
-    const float* xc = x + (long)b * bs + t;
-    const float* rc = res ? res + (long)b * bs + t : nullptr;
+    const float* xc = x + ls.base(b, bs) + t;
+    const float* rc = res ? res + ls.base(b, bs) + t : nullptr;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += xc[(long)c * pitch] + (rc ? rc[(long)c * pitch] : 0.f);
     const float mean = s / C;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void layernorm_cols_serial_kernel(const float* 
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(q / C + eps);
-    float* yc = y + (long)b * ybs + t;
+    float* yc = y + ls.base(b, ybs) + t;
     const float* g = gb ? gb + (long)b * gbstride + goff : nullptr;
     for (int c = 0; c < C; ++c) {
         float v = (xc[(long)c * pitch] + (rc ? rc[(long)c * pitch] : 0.f) - mean) * rstd;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void albert_embed_kernel(const int64_t* ids, in
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(q / 128.f + eps);
-    float* yc = y + (long)b * ybs + t;
+    float* yc = y + ls.base(b, ybs) + t;
     for (int c = 0; c < 128; ++c) yc[(long)c * ypitch] = ((wv[c] + type0[c]) + pv[c] - mean) * rstd * lnw[c] + lnb[c];
 }
 void launch_albert_embed(const int64_t* ids, int Tmax, const float* word, const float* pos, const float* type0,
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, long qb
     const int q0 = blockIdx.x * 32;
     if (q0 >= T) return;
     const int HD = heads * 64;
-    const float* qb = qkv + (long)b * qbs + (long)(hd * 64) * qpitch;
+    const float* qb = qkv + ls.base(b, qbs) + (long)(hd * 64) * qpitch;
     const float* kb = qb + (long)HD * qpitch;
     const float* vb = kb + (long)HD * qpitch;
     const int tq = min(q0 + l31, T - 1);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, long qb
     }
     if (q0 + l31 < T) {
         const float inv = 1.0f / l;
-        float* cb = ctx + (long)b * cbs + (long)(hd * 64) * cpitch + q0 + l31;
+        float* cb = ctx + ls.base(b, cbs) + (long)(hd * 64) * cpitch + q0 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gbs, i
     const int dir = blockIdx.x, b = blockIdx.y, j = threadIdx.x & 255, pt = threadIdx.x >> 8;
     const int T = ls.len(b);
     const float4* W = reinterpret_cast<const float4*>(whh) + (long)dir * 256 * 256 + (long)(64 * pt) * 256 + j;
-    const float* g0 = gx + (long)b * gbs + (long)(dir * 1024 + j) * gpitch;
+    const float* g0 = gx + ls.base(b, gbs) + (long)(dir * 1024 + j) * gpitch;
     const long gs = (long)256 * gpitch;
-    float* yo = y + (long)b * ybs + (long)(dir * 256 + j) * ypitch;
+    float* yo = y + ls.base(b, ybs) + (long)(dir * 256 + j) * ypitch;
     float c = 0.f;
     if (pt == 0) hbuf[0][j] = 0.f;
     float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -464,9 +464,9 @@ __global__ __launch_bounds__(512, 1) void lstm_split_kernel(const float* gx, lon
     int Tf = 0;
 #pragma unroll
     for (int n = 0; n < NS; ++n) Tf = (fn == n) ? Tn[n] : Tf;
-    const float* g0 = gx + (long)fb * gbs + (long)(dir * 1024 + j) * gpitch;
+    const float* g0 = gx + ls.base(fb, gbs) + (long)(dir * 1024 + j) * gpitch;
     const long gs = (long)256 * gpitch;
-    float* yo = y + (long)fb * ybs + (long)(dir * 256 + j) * ypitch;
+    float* yo = y + ls.base(fb, ybs) + (long)(dir * 256 + j) * ypitch;
     // exchange buffer: one 8-byte (value, step) word per hidden unit, sentence and step parity
     unsigned long long* H = reinterpret_cast<unsigned long long*>(hx) + (long)(grp * 2 + dir) * (2 * NS * 256);
     float c = 0.f;
@@ -569,7 +569,7 @@ __global__ void fill_rows_kernel(float* y, long ybs, int ypitch, int r0, const f
                                  LenSpec ls) {
     const int b = blockIdx.z, i = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
     if (t >= ls.len(b)) return;
-    y[(long)b * ybs + (long)(r0 + i) * ypitch + t] = v[(long)b * vstride + voff + i];
+    y[ls.base(b, ybs) + (long)(r0 + i) * ypitch + t] = v[(long)b * vstride + voff + i];
 }
 void launch_fill_rows(float* y, long ybs, int ypitch, int r0, int n, const float* v, int vstride, int voff,
                       LenSpec ls, int B, int Tmax, hipStream_t s) {
@@ -593,13 +593,13 @@ void launch_copy_rows(const float* x, long xbs, int xpitch, float* y, long ybs, 
 // sigmoids are rounded to fp32 one by one (as torch does), summed in fp64 and rounded once,
 // so the sum is the correctly rounded value of what any fp32 summation order approximates.
 __global__ void durations_kernel(const float* logits, long lbs, int lpitch, int ndur, const float* speed,
-                                 const int* lens, int Tmax, int* dur, float* raw) {
+                                 const int* lens, int Tmax, int* dur, float* raw, const int* loff) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
     if (t >= Tmax) return;
     int d = 0;
     float r = 0.f;
     if (t < lens[b]) {
-        const float* lg = logits + (long)b * lbs + t;
+        const float* lg = logits + (loff ? (long)loff[b] : (long)b * lbs) + t;
         double s = 0.0;
         for (int k = 0; k < ndur; ++k) s += (double)sigmoidf_(lg[(long)k * lpitch]);
         r = __fdiv_rn((float)s, speed[b]);
@@ -610,9 +610,9 @@ __global__ void durations_kernel(const float* logits, long lbs, int lpitch, int 
     raw[(long)b * Tmax + t] = r;
 }
 void launch_durations(const float* logits, long lbs, int lpitch, int ndur, const float* speed, const int* lens,
-                      int B, int Tmax, int* dur, float* raw, hipStream_t s) {
+                      int B, int Tmax, int* dur, float* raw, hipStream_t s, const int* loff) {
     hipLaunchKernelGGL(durations_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, logits, lbs, lpitch, ndur, speed,
-                       lens, Tmax, dur, raw);
+                       lens, Tmax, dur, raw, loff);
 }
 
 // -------------------------------------------------------- alignment + gather (row a9)
@@ -646,13 +646,13 @@ void launch_alignment(const int* dur, int Tmax, const int* lens, int B, int* idx
 // the frame-rate write.  Rows are padded to 4 floats: a float4 that starts inside the row is stored whole.
 #define GATHER_GC 8
 __global__ __launch_bounds__(256) void gather_kernel(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch,
-                                                     const int* nfr, float* y, long ybs, int ypitch) {
+                                                     const int* nfr, float* y, long ybs, int ypitch, const int* xoff) {
     const int b = blockIdx.z, c0 = blockIdx.y * GATHER_GC, f = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int F = nfr[b];
     if (f >= F) return;
     const int4 i4 = *reinterpret_cast<const int4*>(idx + (long)b * ipitch + f);
     const int i0 = i4.x, i1 = f + 1 < F ? i4.y : i0, i2 = f + 2 < F ? i4.z : i0, i3 = f + 3 < F ? i4.w : i0;
-    const float* xb = x + (long)b * xbs;
+    const float* xb = x + (xoff ? (long)xoff[b] : (long)b * xbs);
     float* yb = y + (long)b * ybs + f;
 #pragma unroll
     for (int k = 0; k < GATHER_GC; ++k) {
@@ -662,10 +662,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* x, long xbs, i
     }
 }
 void launch_gather(const float* x, long xbs, int xpitch, int C, const int* idx, int ipitch, const int* nfr, float* y,
-                   long ybs, int ypitch, int B, int Fmax, hipStream_t s) {
+                   long ybs, int ypitch, int B, int Fmax, hipStream_t s, const int* xoff) {
     // host-checked: ipitch, ypitch multiples of 4 (int4 / float4 accesses), Fmax <= ipitch
     hipLaunchKernelGGL(gather_kernel, dim3(DIVUP(DIVUP(Fmax, 4), 256), DIVUP(C, GATHER_GC), B), dim3(256), 0, s, x, xbs,
-                       xpitch, C, idx, ipitch, nfr, y, ybs, ypitch);
+                       xpitch, C, idx, ipitch, nfr, y, ybs, ypitch, xoff);
 }
 
 // ------------------------------------------- depthwise ConvTranspose1d k3 s2 p1 op1 ("pool")

@@ -64,6 +64,8 @@ class Engine:
         self.config = config or spec.DEFAULT_CONFIG
         self.device = device
         self.h = C.c_void_p()
+        self._parent = None                # Engine.fork(): the engine whose weights this one reads
+        self._forks = []
         cfg = _cfg_struct(self.config)
         rc = self.lib.k82_create(C.byref(cfg), device, C.byref(self.h))
         if rc != 0:
@@ -76,6 +78,30 @@ class Engine:
         self._check(self.lib.k82_finalize(self.h))
         self.set_precision(precision)
 
+    def fork(self):
+        """k82_fork: a second execution context on THIS engine's weights (own stream, workspace and phase-1 state; no
+        second upload).  Calls on the two objects do not serialise against each other: a thread per object overlaps one
+        batch's token-rate phase with another batch's frame-rate phase on the same GPU (BatchSynthesizer(contexts=2)).
+        Same kernels and launch rules, so a batch gives the same bits on either.  Close forks before their parent."""
+        if self._parent is not None:
+            raise RuntimeError("Engine.fork: fork the engine that owns the weights, not one of its forks")
+        child = object.__new__(Engine)
+        child.lib = self.lib
+        child._lock = threading.RLock()
+        child.host_alloc_s = 0.0
+        child._pending = None
+        child.config, child.device = self.config, self.device
+        child._parent = self
+        child._forks = []
+        child.h = C.c_void_p()
+        with self._lock:
+            rc = self.lib.k82_fork(self.h, C.byref(child.h))
+            if rc != 0:
+                raise RuntimeError(f"k82_fork failed ({rc}): {self.lib.k82_last_error(None).decode()}")
+            child.precision = self.precision
+            self._forks.append(child)
+        return child
+
     def set_precision(self, precision):
         """"fp32" (default), "bf16" (bf16 MFMA for the decoder / generator convolutions) or "bf16x3" (the same
         convolutions with every operand split into two bf16 numbers and three MFMAs per product: fp32-grade
@@ -83,6 +109,8 @@ class Engine:
         mode = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}[precision]
         self._check(self.lib.k82_set_precision(self.h, mode))
         self.precision = ("fp32", "bf16", "bf16x3")[mode]
+        for f in self._forks:              # the contexts of one engine compute in one mode
+            f.set_precision(precision)
 
     def reserve(self, batch, tokens, frames):
         """k82_reserve: size the workspace once for batches up to ``batch`` sentences x ``tokens`` tokens x ``frames``
@@ -108,8 +136,13 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
+            for f in list(getattr(self, "_forks", ())):      # forks read this engine's weights: they go first
+                f.close()
             self.lib.k82_destroy(self.h)
             self.h = C.c_void_p()
+            par = getattr(self, "_parent", None)
+            if par is not None and self in par._forks:
+                par._forks.remove(self)
 
     def __del__(self):
         try:

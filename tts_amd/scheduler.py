@@ -8,6 +8,7 @@ final ordered gather of variable-length audio.  No collective touches the forwar
 """
 from __future__ import annotations
 
+import threading
 import time
 
 import numpy as np
@@ -74,7 +75,7 @@ class BatchSynthesizer:
     returns audio per sentence, in input order."""
 
     def __init__(self, engine, max_batch: int = 64, max_tokens: int = 64 * 256, frame_budget: int = 160_000,
-                 frame_pad_limit: float = 3.0, output: str = "host"):
+                 frame_pad_limit: float = 3.0, output: str = "host", contexts: int = 1):
         """Two-phase execution: batches are formed by token count, phase 1 predicts the
         durations, and a batch whose PREDICTED frame counts are too ragged -- padded frames B * Fmax above
         ``frame_pad_limit`` x the real frames, or more real frames than ``frame_budget`` -- is re-bucketed by F: its
@@ -91,50 +92,70 @@ class BatchSynthesizer:
         # it into a device buffer, k82_pcm16 converts it there (clip(x, -1, 1) * 32767 -> int16, the reference's playback
         # format: basic.tts_kokoro_2_play_pause_works.py:25), and the per-sentence results are int16 views of that device
         # buffer, ready for ordered_gather_pcm16 to send over RCCL or copy to the host once, at half the bytes.
+        # contexts > 1: that many execution contexts on the engine's weights (Engine.fork: own stream, workspace and
+        # phase-1 state each), one host thread per context, batches handed out in order.  While one context sits in a
+        # batch's token-rate phase (a hundred small launches that cannot fill the chip, then a device -> host sync for
+        # the predicted durations) or in host code (packing, page-locked buffers), the other one's frame-rate kernels
+        # run: phase 1 of batch i+1 overlaps phase 2 of batch i ("two-phase execution ...
+        # per-GPU queues"; the look-ahead intent of speech7.py:218-258).  Batch composition is the same as with one
+        # context and a batch gives the same bits on any context, so the audio is bit-identical.
+        if contexts < 1:
+            raise ValueError("contexts must be >= 1")
         self.output = output
         self.engine = engine
+        self.engines = [engine] + [engine.fork() for _ in range(contexts - 1)]
+        self._stats_lock = threading.Lock()
         self.max_batch, self.max_tokens, self.frame_budget = max_batch, max_tokens, frame_budget
         self.frame_pad_limit = frame_pad_limit
         self.stats = {"batches": 0, "rebucketed": 0, "frames": 0, "padded_frames": 0,
                       "s_pack": 0.0, "s_durations": 0.0, "s_decode": 0.0}
 
-    def _run(self, id_lists, ref_rows, speeds, seeds, out, where):
+    def _add(self, **kw):
+        with self._stats_lock:
+            for k, v in kw.items():
+                self.stats[k] += v
+
+    def close(self):
+        """Destroys the forked contexts (the engine itself stays the caller's)."""
+        for e in self.engines[1:]:
+            e.close()
+        self.engines = self.engines[:1]
+
+    def _run(self, id_lists, ref_rows, speeds, seeds, out, where, engine=None):
+        engine = engine or self.engine
         t0 = time.perf_counter()
-        ids, lens = self.engine.pack(id_lists)
+        ids, lens = engine.pack(id_lists)
         refs = np.stack(ref_rows)
-        self.stats["s_pack"] += time.perf_counter() - t0
+        self._add(s_pack=time.perf_counter() - t0)
         # the durations -> decode pair shares state inside the handle: one critical section per batch, so two threads
         # on one engine (epubviewer_06_latest_1_nov_2025_theme.py:407,692,715) interleave whole batches, never halves
-        with self.engine.session():
+        with engine.session():
             t0 = time.perf_counter()
-            pred, nfr = self.engine.durations(ids, lens, refs, speed=np.asarray(speeds, np.float32))
-            self.stats["s_durations"] += time.perf_counter() - t0
+            pred, nfr = engine.durations(ids, lens, refs, speed=np.asarray(speeds, np.float32))
+            self._add(s_durations=time.perf_counter() - t0)
             real, padded = int(nfr.sum()), int(nfr.max()) * len(id_lists)
             split = len(id_lists) > 1 and (real > self.frame_budget or padded > self.frame_pad_limit * real)
             if not split:
                 t0 = time.perf_counter()
                 if self.output == "pcm16_device":
                     import torch
-                    dev = torch.device("cuda", self.engine.device)
+                    dev = torch.device("cuda", engine.device)
                     n = real * spec.FRAME_SAMPLES
                     f32 = torch.empty((n,), dtype=torch.float32, device=dev)
                     audio = torch.empty((n,), dtype=torch.int16, device=dev)
-                    _, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64), out=(f32.data_ptr(), n))
-                    self.engine.pcm16_device(f32.data_ptr(), audio.data_ptr(), n)
+                    _, off = engine.decode(seeds=np.asarray(seeds, dtype=np.uint64), out=(f32.data_ptr(), n))
+                    engine.pcm16_device(f32.data_ptr(), audio.data_ptr(), n)
                     del f32
                 else:
-                    audio, off = self.engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
-                self.stats["s_decode"] += time.perf_counter() - t0
-                self.stats["batches"] += 1
-                self.stats["frames"] += real
-                self.stats["padded_frames"] += padded
+                    audio, off = engine.decode(seeds=np.asarray(seeds, dtype=np.uint64))
+                self._add(s_decode=time.perf_counter() - t0, batches=1, frames=real, padded_frames=padded)
         if split:                                                # second-phase re-bucketing by predicted F
-            self.stats["rebucketed"] += 1
+            self._add(rebucketed=1)
             order = sorted(range(len(id_lists)), key=lambda k: (int(nfr[k]), k))
             h = len(order) // 2
             for part in (order[:h], order[h:]):
                 self._run([id_lists[k] for k in part], [ref_rows[k] for k in part], [speeds[k] for k in part],
-                          [seeds[k] for k in part], out, [where[k] for k in part])
+                          [seeds[k] for k in part], out, [where[k] for k in part], engine)
             return
         for k, w in enumerate(where):
             out[w] = (audio[off[k]:off[k + 1]], pred[k, :lens[k]].copy())     # views of the batch buffer: no second copy
@@ -147,9 +168,38 @@ class BatchSynthesizer:
         seeds = list(range(n)) if seeds is None else list(seeds)
         counts = [len(x) + 2 for x in id_lists]
         out = {}
-        for batch in make_batches(indices, counts, self.max_batch, self.max_tokens):
+        batches = make_batches(indices, counts, self.max_batch, self.max_tokens)
+
+        def run(batch, engine):
             self._run([id_lists[i] for i in batch], [ref_rows[i] for i in batch], [speeds[i] for i in batch],
-                      [seeds[i] for i in batch], out, batch)
+                      [seeds[i] for i in batch], out, batch, engine)
+
+        if len(self.engines) == 1 or len(batches) < 2:
+            for batch in batches:
+                run(batch, self.engine)
+            return out
+        # one host thread per context; batches are handed out in order (heaviest first), results land in `out` by index
+        nxt, lock, errors = [0], threading.Lock(), []
+
+        def worker(engine):
+            try:
+                while not errors:
+                    with lock:
+                        k = nxt[0]
+                        nxt[0] += 1
+                    if k >= len(batches):
+                        return
+                    run(batches[k], engine)
+            except BaseException as e:                            # re-raised in the caller's thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(e,), name=f"k82-context-{k}") for k, e in enumerate(self.engines)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
         return out
 
 
