@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the B = 1 latency loop and the other-precision legs")
     ap.add_argument("--latency-sentences", type=int, default=45)
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic on this box")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the pass rocprofv3 runs: one step, no JSON extras
     ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32",
                     help="fp32 (BASELINE configs[1], the default); bf16 MFMA in the decoder/generator (cfg3's dtype); "
                          "bf16x3: the same convolutions with split operands, three bf16 MFMAs per product (fp32-grade)")
@@ -157,12 +160,18 @@ def main():
         # HBM bytes per launch of the dominant kernel family come from the committed rocprofv3 PMC passes of this
         # same command (counters cannot be read from inside the process); see profiles/*_traffic.json.
         traffic, traffic_src = None, None
+        under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+        if world == 1 and not args.no_traffic and not args.traffic_child and not under_profiler:
+            traffic, traffic_src = measure_traffic(args)
+        elif under_profiler:
+            traffic_src = "this run is itself under a profiler"
         tname = {"fp32": "r03_traffic.json", "bf16": "r03_traffic_bf16.json"}.get(args.dtype)
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname or "")
-        if tname and os.path.exists(tp) and B == 64 and T == 256:
+        if traffic is None and tname and os.path.exists(tp) and B == 64 and T == 256:
             with open(tp) as fh:
                 traffic = json.load(fh)["conv_mfma_2x2_family"]["traffic_bytes_per_launch_corrected"]
-            traffic_src = f"profiles/{tname}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes (tools/make_traffic.py)"
+            traffic_src = (f"profiles/{tname} (a committed builder-run figure, NOT measured in this run: " + (traffic_src or "PMC passes skipped") +
+                           "): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes (tools/make_traffic.py)")
         out = {
             "metric": "audio-sec synthesized/sec (node) Kokoro-82M",
             "value": audio_all * args.steps / dt,
@@ -210,6 +219,57 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_traffic(args, timeout_s=200):
+    """roofline.traffic of THIS box: HBM bytes per launch of the dominant kernel family from the PMC counters, collected
+    as MI355X_MICROARCH.md prescribes -- two separate child runs, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    (nothing else on the command line), each over one step of this same workload (`--traffic-child`: one sizing pass
+    + one step, no extras); both counters are KB per dispatch and FETCH_SIZE reads half of wide coalesced reads on
+    gfx950, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The children are fresh processes started with
+    subprocess (this one keeps running and is not replaced); the program after `--` is python3 itself.
+    Returns (bytes per launch, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="k82_pmc_")
+    sums, launches = {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-child", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--dtype", args.dtype,
+                   "--batch", str(args.batch), "--tokens", str(args.tokens)]
+            env = dict(os.environ, TMPDIR=tmp)
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass exited with {r.returncode}"
+            per = {}
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        k = row["Kernel_Name"]
+                        # the 128-row family the roofline object is about (every wave shape of it), not the 32 / 64-row kernels
+                        if row["Counter_Name"] == counter and "conv_mfma_kernel" in k and "<1, 4," not in k:
+                            key = row["Dispatch_Id"]
+                            per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, f"the --pmc {counter} pass recorded no conv_mfma_kernel dispatch"
+            sums[counter] = sum(per.values())
+            launches = len(per)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return ((2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0 / launches,
+            f"measured in this run: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over one step of this workload "
+            f"({launches} launches of the family incl. the sizing pass); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction, MI355X_MICROARCH.md)")
 
 
 def extras(eng, args, step, audio_s):

@@ -147,8 +147,10 @@ int k82_reserve(k82_handle* h, int B, int Tmax, int64_t frames);
 /* Compute precision of the frame-rate convolutions (decoder + generator; SURVEY.md 8d cfg3 "bf16 decoder").
  *   mode 0 (default): every convolution on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
  *   mode 1: the decoder / generator convolutions round weights and staged activations to bf16 and use
- *           v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations stay fp32 in HBM; durations, the F0/N
- *           curves, the harmonic source, conv_post and the iSTFT stay fp32 (durations remain bit-exact).
+ *           v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the resblock-internal tensor of every generator
+ *           AdaINResBlock1 crosses HBM as bf16 channel pairs, every other activation (residual paths included) stays
+ *           fp32; durations, the F0/N curves, the harmonic source, conv_post and the iSTFT stay fp32 (durations
+ *           remain bit-exact).  Waveform SNR against mode 0: 46 dB.
  *   mode 2: "bf16x3" -- the same convolutions with every operand split into two bf16 numbers (hi + lo, 2^-17
  *           relative) and three bf16 MFMAs per product (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulation):
  *           fp32-grade results (waveform within 1e-5 of the CPU oracle; the fp32 bar is 1e-3) at 2.2x the mode-0

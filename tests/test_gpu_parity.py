@@ -578,6 +578,9 @@ def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
     loop's order, so an engine built with K82_RING=0 (generic loop everywhere) must reproduce durations and audio
     exactly on a ragged batch that crosses every tap count (3, 7, 11), both channel widths and all three epilogues."""
     from tts_amd.engine import Engine
+    # (t1 stays fp32 in HBM on both sides: bf16 activations in HBM exist in the ring kernels only and round once more --
+    # test_bf16_activations_in_hbm covers them)
+    monkeypatch.setenv("K82_T1_BF16", "0")
     # the long batch runs the generator stages on the 4 x 2-wave ring (128 x 256 tiles: launches with at least two rounds
     # of them), the short one keeps every launch on the 4 x 1-wave ring
     for lengths, wide in (([37, 90, 12, 200, 65], True), ([9, 14], False)):
@@ -605,6 +608,46 @@ def test_bf16_ring_pipeline_gives_the_generic_loops_bits(monkeypatch):
                 eng.close()
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
         assert np.array_equal(out[0][1], out[1][1]), float(np.abs(out[0][1] - out[1][1]).max())
+
+
+@pytest.mark.gpu
+def test_bf16_activations_in_hbm(monkeypatch):
+    """bf16 mode (north_star: "bf16 ... LDS-staged tiles"): the resblock-internal tensor t1 of every AdaINResBlock1 crosses
+    HBM as bf16 channel pairs in the staged tile's own operand order (ConvP::y_b16 / x_b16; conv_mfma.hip epilogue_b16, XB
+    staging) -- half the store and the load of that tensor.  Against an engine that keeps t1 in fp32 (K82_T1_BF16=0):
+    durations and offsets identical (the duration branch never leaves fp32), the audio differs (t1 is rounded once more)
+    by far less than the mode's own distance from fp32, and the north-star bar (SNR >= 40 dB against the fp32 mode)
+    holds with margin on a ragged batch that takes all three ring shapes and all three tap counts."""
+    from tts_amd.engine import Engine
+    lengths = [37, 90, 12, 200, 65, 180, 150, 120]
+    id_lists, ref_s = H.make_batch(29, lengths)
+    seeds = np.arange(len(lengths), dtype=np.uint64) + 300
+    out = {}
+    for tag, env, prec in (("b16", "1", "bf16"), ("f32t1", "0", "bf16"), ("fp32", "1", "fp32")):
+        monkeypatch.setenv("K82_T1_BF16", env)
+        eng = Engine(spec.synthetic_state_dicts(0), precision=prec)
+        try:
+            ids, lens = eng.pack(id_lists)
+            with eng.session():
+                pred, _ = eng.durations(ids, lens, ref_s)
+                audio, off = eng.decode(seeds=seeds)
+            out[tag] = (pred, audio.copy(), off)
+        finally:
+            eng.close()
+    for tag in ("f32t1", "fp32"):
+        assert np.array_equal(out["b16"][0], out[tag][0]) and np.array_equal(out["b16"][2], out[tag][2])
+    assert not np.array_equal(out["b16"][1], out["f32t1"][1])          # the bf16 tensor really was in the path
+    off = out["b16"][2]
+
+    def snr(ref, x):
+        ref, x = ref.astype(np.float64), x.astype(np.float64)
+        return 10 * np.log10((ref ** 2).sum() / max(((ref - x) ** 2).sum(), 1e-300))
+
+    for b in range(len(lengths)):
+        sl = slice(off[b], off[b + 1])
+        s_mode, s_old, s_t1 = snr(out["fp32"][1][sl], out["b16"][1][sl]), snr(out["fp32"][1][sl], out["f32t1"][1][sl]), snr(out["f32t1"][1][sl], out["b16"][1][sl])
+        print(f"sentence {b}: bf16 mode vs fp32 {s_mode:.1f} dB (t1 in fp32: {s_old:.1f} dB); t1 bf16 vs t1 fp32 {s_t1:.1f} dB")
+        assert s_mode >= 40.0 and s_mode >= s_old - 3.0, (b, s_mode, s_old)
 
 
 @pytest.mark.gpu

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 n=$1; dt=${2:-fp32}
 for r in 1 2; do for ((v=0; v<n; v++)); do
   echo "== variant $v (round $r)"
-  K82_LIB_PATH=$PWD/tts_amd/libk82_v$v.so timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline --dtype $dt 2>/dev/null | python -c "
+  K82_LIB_PATH=$PWD/tts_amd/libk82_v$v.so timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --dtype $dt 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -208,7 +208,8 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // encoder: < 3 % of the FLOPs), whose noise reaches the rounded durations and the F0 curve that the harmonic source
 // integrates into a phase.  Costs 16 * HT * HTN more registers and two vector instructions per accumulator and block.
 // The fold points are positions in K, the same for every tile shape: shapes stay bit-identical to each other.
-template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT, bool KSPLIT = false>
+// XB / YB (bf16 ring kernels): the input / output tensor lives in HBM as bf16 channel pairs (ConvP::x_b16 / y_b16).
+template <int WM, int WN, int HT, int EPI, bool SNAKE, int PREC, int KCT = 16, int TAPS = 0, int HTN = HT, bool KSPLIT = false, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HTN > 4 ? 1 : K82_OCC_RING) : PREC == 1 ? K82_OCC_BF16 : PREC == 2 ? K82_OCC_SPLIT : K82_OCC_F32) void conv_mfma_kernel(ConvP p) {
     constexpr bool BF16 = PREC != PREC_F32;        // bf16 matrix instruction, 16-byte A fragments
     constexpr bool SPLIT = PREC == PREC_SPLIT;
@@ -216,6 +217,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     constexpr int BM = WT * WM, BN = WTN * WN, KC = KCT, WP = BN + 68, NW = WM * WN;
     static_assert(KC == 16 || (KC == 32 && HT == 1 && !BF16), "32-channel tiles: small-launch fp32 kernel only");
     static_assert(!KSPLIT || (PREC == PREC_F32 && TAPS == 0), "blocked summation: the fp32 two-set loop only");
+    static_assert(!(XB || YB) || (PREC == PREC_BF16 && TAPS > 0 && HT == 1 && HTN == 4 && SNAKE), "bf16 activations in HBM: the bf16 ring kernels of the Snake convs only");
+    static_assert(!YB || EPI == EPI_PLAIN, "bf16 output: plain epilogue only");
     static_assert(HT == 2 || (HT == 1 && (!BF16 || HTN == 4)), "one MFMA tile row per wave: the fp32 small-launch shape and the 32 x 128 bf16 shapes");
     constexpr int CPW = KC / NW;               // channels staged per wave
     constexpr int NCOL = (WP / 4 + 63) / 64;   // float4 sweeps (64 lanes x 4 columns) per channel
@@ -319,6 +322,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     auto chan = [&](int cc) -> int { return BF16 ? 2 * (wave + NW * (cc >> 1)) + (cc & 1) : wave + cc * NW; };
     static_assert(!BF16 || (NW * CPW == 16 && CPW % 2 == 0), "the packed bf16 staging: every wave carries whole channel pairs of a 16-channel tile");
     float4 raw[CPW][NCOL], nmr[CPW];
+    uint4 rawb[CPW / 2 > 0 ? CPW / 2 : 1][NCOL];            // XB: the loads of a channel PAIR row (4 columns x 2 channels per lane)
+    auto xb_half = [](unsigned d, int h) -> float { return __uint_as_float(h ? (d & 0xffff0000u) : (d << 16)); };
     float alr[CPW], ialr[CPW];
     // Per-channel transform parameters always come from a readable address (the padded bias vector stands
     // in when there is no AdaIN / Snake), so they are prefetched unconditionally with the tile.
@@ -337,14 +342,27 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
         // tile's last float4 (same cache line as their neighbour's) instead of pulling the next tile's columns through
         // L2 and HBM (round 2 measured 2.2x the algorithmic read traffic on the Snake convs, profiles/r02_v6_traffic.json)
         const int tlast = min(((T.Lin - 1) >> 2) << 2, T.tbase + wlast);
+        if constexpr (XB) {
+#pragma unroll
+            for (int pr = 0; pr < CPW / 2; ++pr) {
+                const unsigned* xr = reinterpret_cast<const unsigned*>(xb) + (long)((ci0 >> 1) + wave + NW * pr) * p.xpitch;   // (cin % 16 == 0: every pair is real)
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) {
+                    const int t = min(max(T.tbase + 4 * (lane + 64 * k), 0), tlast);
+                    rawb[pr][k] = *reinterpret_cast<const uint4*>(xr + t);
+                }
+            }
+        }
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const int ci = min(ci0 + chan(cc), p.cin - 1);
             const float* xr = xb + (long)ci * p.xpitch;
+            if constexpr (!XB) {
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 const int t = min(max(T.tbase + 4 * (lane + 64 * k), 0), tlast);
                 raw[cc][k] = *reinterpret_cast<const float4*>(xr + t);
+            }
             }
             if (params) {
                 nmr[cc] = normp[(long)T.b * nstride + min(ci, nclamp)];
@@ -399,7 +417,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
                         out[cc][k][2 * h + 1] = (t + 2 * h + 1 < lin) ? u.y : 0.f;
                     }
                 } else {
-                    const float v[4] = {raw[cc][k].x, raw[cc][k].y, raw[cc][k].z, raw[cc][k].w};
+                    float v[4];
+                    if constexpr (XB) {
+                        const uint4 d = rawb[cc >> 1][k];
+                        v[0] = xb_half(d.x, cc & 1); v[1] = xb_half(d.y, cc & 1); v[2] = xb_half(d.z, cc & 1); v[3] = xb_half(d.w, cc & 1);
+                    } else {
+                        v[0] = raw[cc][k].x; v[1] = raw[cc][k].y; v[2] = raw[cc][k].z; v[3] = raw[cc][k].w;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float u = fmaf(v[e], sc, of);
@@ -738,8 +762,56 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             }
         }
     };
+    // YB: the output goes to HBM as bf16 channel pairs (ConvP::y_b16).  Per 32 x 32 accumulator tile a lane takes the
+    // PAIR of rows (2 pr, 2 pr + 1), pr = lane / 8 + 8 q, and four columns: two float4 reads of the patch, one 16-byte
+    // store of four packed dwords -- half the store instructions and bytes of the fp32 epilogue.  The statistics partials
+    // are those of the fp32 values, in the order the fp32 epilogues sum them (same bits as with an fp32 t1).
+    auto epilogue_b16 = [&](const Tile& T, const EpiArgs& E) {
+        const int p0 = lane >> 3, c4 = (lane & 7) * 4;
+        unsigned* const yb = reinterpret_cast<unsigned*>(E.y + (long)T.b * E.ybs);
+#pragma unroll
+        for (int idx = 0; idx < HT * HTN; ++idx) {
+            const int mi = idx / HTN, ni = idx % HTN;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
+            const int t = T.n0 + nw + ni * 32 + c4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int pr = p0 + 8 * q;                      // pair row inside the 32-row tile
+                float v[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * pr + h;
+                    const float4 v4 = *reinterpret_cast<const float4*>(patch + i * 36 + c4);
+                    const float bs = bsh[mi * 32 + i];
+                    v[h][0] = (v4.x + bs) * E.out_scale; v[h][1] = (v4.y + bs) * E.out_scale;
+                    v[h][2] = (v4.z + bs) * E.out_scale; v[h][3] = (v4.w + bs) * E.out_scale;
+                    if (E.stat) {                               // wave-uniform
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float u = (t + e < T.Lout) ? v[h][e] : 0.f;
+                            s1 += u;
+                            s2 = fmaf(u, u, s2);
+                        }
+                        s1 = sum8(s1);
+                        s2 = sum8(s2);
+                        if (c4 == 0 && t < T.Lout)
+                            E.stat[(long)T.b * E.sbs + (long)(T.m0 + mi * 32 + i) * E.snt + (t >> 5)] = make_float2(s1, s2);
+                    }
+                }
+                if (t < T.Lout)                                 // (rows: cout % 32 == 0, host-checked)
+                    *reinterpret_cast<uint4*>(yb + (long)(((T.m0 + mi * 32) >> 1) + pr) * E.ypitch + t) =
+                        make_uint4(pack_bf16(v[0][0], v[1][0]), pack_bf16(v[0][1], v[1][1]), pack_bf16(v[0][2], v[1][2]), pack_bf16(v[0][3], v[1][3]));
+            }
+        }
+    };
     auto epilogue = [&](const Tile& T, float bias_l) {
         bsh[lane] = bias_l;
+        if constexpr (YB) {
+            epilogue_b16(T, epi_args());
+            return;
+        }
         if constexpr (EPI != EPI_SCALAR) {
             const EpiArgs E = epi_args();
             const long yb = (long)T.b * E.ybs, rb = (long)T.b * E.rbs, ab = (long)T.b * E.abs_;
@@ -959,7 +1031,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int cc = 2 * pr + h;
-                const float v = e == 0 ? raw[cc][k].x : e == 1 ? raw[cc][k].y : e == 2 ? raw[cc][k].z : raw[cc][k].w;
+                float v;
+                if constexpr (XB) {
+                    const unsigned d = e == 0 ? rawb[pr][k].x : e == 1 ? rawb[pr][k].y : e == 2 ? rawb[pr][k].z : rawb[pr][k].w;
+                    v = xb_half(d, h);
+                } else {
+                    v = e == 0 ? raw[cc][k].x : e == 1 ? raw[cc][k].y : e == 2 ? raw[cc][k].z : raw[cc][k].w;
+                }
                 float w = fmaf(v, scx[cc], ofx[cc]);
                 if constexpr (SNAKE) w = snake_fast(w, arx[cc], ialx[cc]);
                 else w = fmaxf(w, w * slope);
@@ -1244,8 +1322,27 @@ static std::atomic<long> g_shape_launches[CONV_NSHAPE];
 long conv_shape_launches(int shape) { return shape >= 0 && shape < CONV_NSHAPE ? g_shape_launches[shape].load() : -1; }
 static inline unsigned ncu(const ConvP& p) { return p.cus > 0 ? (unsigned)p.cus : 256u; }
 
+// the bf16 ring kernels of the Snake convs with t1 as bf16 channel pairs in HBM: the producer (plain epilogue, y_b16) and
+// the consumer (residual / running-mean epilogue, x_b16)
+template <int WM, int WN, int TAPS>
+static bool launch_b16(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
+    if (p.y_b16 && !p.x_b16 && epi == EPI_PLAIN)
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 1, EPI_PLAIN, true, PREC_BF16, 16, TAPS, 4, false, false, true>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
+    else if (p.x_b16 && !p.y_b16 && epi == EPI_RES)
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 1, EPI_RES, true, PREC_BF16, 16, TAPS, 4, false, true, false>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
+    else if (p.x_b16 && !p.y_b16 && epi == EPI_ACC)
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 1, EPI_ACC, true, PREC_BF16, 16, TAPS, 4, false, true, false>), dim3(grid), dim3(64 * WM * WN), 0, s, p);
+    else return false;
+    return true;
+}
 template <int WM, int WN, bool SNAKE, int BF16, int HT = 2, int KCT = 16, int TAPS = 0, int HTN = HT>
 static void launch_epi(const ConvP& p, int epi, unsigned grid, hipStream_t s) {
+    if constexpr (SNAKE && BF16 == PREC_BF16 && TAPS > 0 && HT == 1 && HTN == 4) {
+        if (p.x_b16 || p.y_b16) {
+            if (!launch_b16<WM, WN, TAPS>(p, epi, grid, s)) fprintf(stderr, "k82: no kernel for this bf16-activation conv (epilogue %d)\n", epi);
+            return;
+        }
+    }
     switch (epi) {
     case EPI_PLAIN:  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_PLAIN, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
     case EPI_RES:    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HT, EPI_RES, SNAKE, BF16, KCT, TAPS, HTN>), dim3(grid), dim3(64 * WM * WN), 0, s, p); break;
@@ -1279,7 +1376,7 @@ static void launch_shape(const ConvP& p, int epi, unsigned grid, hipStream_t s) 
 template <int PREC>
 static bool launch_ring(const ConvP& p, int epi, long total, hipStream_t s) {
     // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
-    if ((p.dbg & 1) || p.tapmask || p.cin_p < 32 || p.cin % 16 != 0) return false;   // (cin % 16: the staging reads its parameters per channel PAIR)   // dbg = 1: K82_RING=0 (A/B switch of the engine)
+    if ((p.dbg & 1) || p.tapmask || p.cin_p < 32 || (p.cin % 16 != 0 && !(p.cin_pad_ok && p.tr == TR_NORM && K82_RING_SMEM))) return false;   // (cin % 16: the staging reads its parameters per channel PAIR)   // dbg = 1: K82_RING=0 (A/B switch of the engine)
     const bool snake = p.act == ACT_SNAKE;
     if (snake && epi == EPI_SCALAR) return false;
     // (Measured and not kept: 4 x 1 waves of 32 x 256 at one workgroup per CU -- weight traffic halves again, but with one

@@ -222,6 +222,7 @@ struct k82_handle : K82Weights {
     int cus = 0;
     bool ring_off = false;             // K82_RING=0: the bf16 modes keep the generic tap loop (A/B and bit-identity tests only)
     bool bm256_off = false;            // K82_BM256=0: no 256 x 128 workgroup tiles (bit-identity tests only)
+    bool t1_b16 = true;                // K82_T1_BF16=0: the bf16 mode keeps the resblock-internal tensor t1 in fp32 in HBM (A/B and bit-identity tests)
     bool fused_stats = true;           // K82_FUSED_STATS=0: every instance-norm statistic from the sweep kernel (A/B only)
     int lstm_split_max_b = 0;          // set in finalize(): CUs / 2 (K82_LSTM_SPLIT_MAX_B=0 selects the streaming kernel everywhere)
     int lstm_spin_limit = 1 << 18;     // polls a split-LSTM workgroup waits for a partner's h (K82_LSTM_SPIN_LIMIT: test hook)
@@ -656,6 +657,7 @@ struct k82_handle : K82Weights {
             lstm_split_max_b = cus / 2;          // 4 sentences per workgroup: one resident round up to CUs / 2 sentences
             if (const char* e = std::getenv("K82_FUSED_STATS")) fused_stats = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_RING")) ring_off = std::atoi(e) == 0;
+            if (const char* e = std::getenv("K82_T1_BF16")) t1_b16 = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_KSPLIT")) precise = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_BM256")) bm256_off = std::atoi(e) == 0;
             // K82_LSTM_SPLIT_MAX_B=0: streaming kernel everywhere -- for deployments that KNOW the GPU is shared
@@ -707,6 +709,11 @@ struct k82_handle : K82Weights {
         REQUIRE(p.act != ACT_SNAKE || p.cout_p >= 64, K82_EINVAL, "no Snake conv with <= 32 output channels is built");
         REQUIRE(p.act != ACT_LEAKY || (p.slope >= 0.f && p.slope <= 1.f), K82_EINVAL, "LeakyReLU slope must be in [0, 1]");
         REQUIRE(p.tr != TR_NORM || p.norm, K82_EINVAL, "norm transform needs statistics");
+        // bf16 activations in HBM exist in the bf16 ring kernels of the Snake convs only (conv_mfma.hip launch_ring's own conditions)
+        REQUIRE(!(p.x_b16 || p.y_b16) || (p.wb && !p.wb_split && !(p.dbg & 1) && !p.tapmask && p.act == ACT_SNAKE && p.tr == TR_NORM && p.cin % 16 == 0 &&
+                                          p.cin_p >= 32 && p.cout % 32 == 0 && (p.taps == 3 || p.taps == 7 || p.taps == 11) && !p.up_s && !p.res_shift &&
+                                          (p.y_b16 ? (p.y && !p.res && !p.accbuf && !p.x_b16) : (p.res != nullptr))),
+                K82_EINVAL, "bf16-activation conv outside the shapes the ring kernels are built for");
         REQUIRE(!p.stat || (p.y && !p.up_s && !p.res_shift && p.snt * 32 >= p.Lmax_out), K82_EINVAL, "statistics partials need a stored, plain-layout output");
         // the lean epilogue addresses a sentence's rows with 32-bit byte offsets
         const long kMaxElems = 1L << 30;
@@ -723,6 +730,8 @@ struct k82_handle : K82Weights {
     float4* stats(const float* x, long xbs, int xpitch, LenSpec ls, int C, const float* gb, int gstride, int goff,
                   Arena& ar, int Lmax, double elems) {
         float4* nm = (float4*)ar.alloc((size_t)B * ru(C, 16) * sizeof(float4));
+        // entries of the padded channels: (mean, rstd, gain, beta) = 0, i.e. "stage an exact zero" (ConvP::cin_pad_ok)
+        if (ru(C, 16) != C) HIPCHK(hipMemsetAsync(nm, 0, (size_t)B * ru(C, 16) * sizeof(float4), st));
         timed(FAM_STATS, elems * 4.0, [&] { launch_adain_stats(x, xbs, xpitch, ls, C, B, gb, gstride, goff, nm, ru(C, 16), Lmax, st); });
         return nm;
     }
@@ -746,7 +755,7 @@ struct k82_handle : K82Weights {
         const int tp = ru(Lo, 4);
         float* t1 = ar.f((size_t)nb * L.cout * tp);
         ConvP p1 = cp(L.c1, c1in, c1bs, c1pitch, t1, (long)L.cout * tp, tp, lo, lo, nb, Lo);
-        if (!L.up) { p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.cin, 16); p1.act = ACT_LEAKY; p1.slope = 0.2f; }
+        if (!L.up) { p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.cin, 16); p1.act = ACT_LEAKY; p1.slope = 0.2f; p1.cin_pad_ok = 1; }
         float4* n2;
         // (not in the F0 / N stacks: F0 sets the phase of the harmonic source, where a rounding of rstd -- harmless for any
         // stage tolerance -- moves the waveform; they keep the all-fp64 sweep)
@@ -807,6 +816,9 @@ struct k82_handle : K82Weights {
             }
             ConvP p1 = cp(L.c1[i], cur, bs, pitch, t1, bs, pitch, ls, ls, B, Lmax, dil[i]);
             if (fs) { p1.stat = part; p1.sbs = (long)L.C * snt; p1.snt = snt; }
+            // bf16 mode: t1 -- written by this conv, read by the next one, by nothing else -- crosses HBM as bf16 channel pairs
+            const bool tb = t1_b16 && fs && bf16_now && precision == 1 && !ring_off && L.C % 32 == 0 && (L.k == 3 || L.k == 7 || L.k == 11);
+            p1.y_b16 = tb ? 1 : 0;
             p1.tr = TR_NORM; p1.norm = n1; p1.nstride = ru(L.C, 16);
             p1.act = ACT_SNAKE; p1.alpha = L.a1[i]; p1.inv_alpha = L.ia1[i];
             run_conv(p1, hbase);
@@ -816,6 +828,7 @@ struct k82_handle : K82Weights {
             p2.tr = TR_NORM; p2.norm = n2; p2.nstride = ru(L.C, 16);
             p2.act = ACT_SNAKE; p2.alpha = L.a2[i]; p2.inv_alpha = L.ia2[i];
             p2.res = cur; p2.rbs = bs; p2.rpitch = pitch;
+            p2.x_b16 = tb ? 1 : 0;
             if (last) { p2.accbuf = accbuf; p2.abs_ = bs; p2.apitch = pitch; p2.acc_init = acc_init; p2.acc_scale = acc_scale; }
             if (i < 2 && fs) { p2.stat = part; p2.sbs = (long)L.C * snt; p2.snt = snt; }
             run_conv(p2, hbase);
@@ -1296,7 +1309,7 @@ int k82_fork(k82_handle* parent, k82_handle** out) {
         static_cast<K82Weights&>(*h) = static_cast<const K82Weights&>(*parent);
         h->scratch = parent->scratch;
         h->cus = parent->cus;
-        h->ring_off = parent->ring_off; h->bm256_off = parent->bm256_off; h->fused_stats = parent->fused_stats; h->precise = parent->precise;
+        h->t1_b16 = parent->t1_b16; h->ring_off = parent->ring_off; h->bm256_off = parent->bm256_off; h->fused_stats = parent->fused_stats; h->precise = parent->precise;
         h->lstm_split_max_b = parent->lstm_split_max_b; h->lstm_spin_limit = parent->lstm_spin_limit; h->conv_spin_limit = parent->conv_spin_limit;
         h->precision = parent->precision;
         h->lstm_err = (int*)h->wmalloc(2 * sizeof(int));        // (wallocs of a fork hold only its own words)

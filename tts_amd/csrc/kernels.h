@@ -57,6 +57,15 @@ struct ConvP {
     int up_s, up_cout_shift, up_off;
     const unsigned* tapmask;                   // per 64-row M tile: bitmask of non-zero taps (nullptr: all)
     int B, Lmax_out;                           // grid extents
+    // bf16 activations in HBM (bf16 mode, resblock-internal tensor t1 of istftnet.AdaINResBlock1): the tensor is stored in
+    // the MFMA-operand order of the staged LDS tile -- [C / 2][pitch] dwords, dword (q, t) = bf16(x[2q][t]) | bf16(x[2q+1][t]) << 16
+    // (round-to-nearest-even) -- in the first half of the fp32 buffer it replaces (same bs, same pitch).  y_b16: this conv
+    // stores its output so (plain epilogue, ring kernels only; the statistics partials are those of the fp32 values);
+    // x_b16: this conv reads its input so (half the bytes through the L1 return path that bounds the ring kernels).
+    int x_b16, y_b16;
+    int cin_pad_ok;                            // 1: the caller zeroed norm[b][cin .. cin_p) (TR_NORM): the padded channels of the last 16-channel
+                                               // tile stage exact zeros without a per-element select, which lets a conv whose cin is not a
+                                               // multiple of 16 (the decoder's 1090- and 514-channel inputs) take the bf16 ring kernels
     int dbg;                                   // test switches of the engine: bit 0 = no ring pipeline (K82_RING=0), bit 1 = no 256 x 128 tiles (K82_BM256=0)
     int kflush;                                // > 0: blocked summation over K (fp32 kernels, conv_mfma.hip KSPLIT) -- the accumulator is folded
                                                // into a second one every kflush 16-channel tiles; 0: one sequential chain
