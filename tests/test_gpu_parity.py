@@ -681,6 +681,40 @@ def test_256_row_tiles_give_the_128_row_tiles_bits(monkeypatch, precision):
 
 
 @pytest.mark.gpu
+def test_split_k_small_launches_give_the_same_bits(monkeypatch):
+    """A single sentence's Linears are chains of dependent global -> LDS -> MFMA steps over K on a few dozen workgroups
+    of an otherwise idle chip (the first-audio path, speech7.py:124-133).  Small fp32 launches of the token-rate and
+    prosody layers are therefore split over K blocks -- the SAME blocks the blocked summation (KSPLIT) folds at -- one
+    workgroup per (tile, block), and a second kernel adds the block sums in block order and applies the epilogue
+    (conv_mfma.hip EPI_PART, splitk_reduce_kernel).  An engine built with K82_SPLITK=0 must reproduce durations, the
+    pre-rounding durations, F0 and audio bit for bit, for one short sentence, one long one, and a small batch."""
+    from tts_amd.engine import Engine
+    for lengths in ([25], [200], [7, 33]):
+        id_lists, ref_s = H.make_batch(31, lengths)
+        seeds = np.arange(len(lengths), dtype=np.uint64) + 5
+        out = []
+        for sw in ("1", "0"):
+            monkeypatch.setenv("K82_SPLITK", sw)
+            eng = Engine(spec.synthetic_state_dicts(0))
+            try:
+                n0 = eng.prof_read("conv_shape_splitk")[1]
+                eng.debug_enable(True)
+                ids, lens = eng.pack(id_lists)
+                with eng.session():
+                    pred, _ = eng.durations(ids, lens, ref_s)
+                    raw = eng.debug_get("duration").copy()
+                    audio, off = eng.decode(seeds=seeds)
+                    f0 = eng.debug_get("F0").copy()
+                out.append((pred, raw, f0, audio.copy(), off))
+                ran = eng.prof_read("conv_shape_splitk")[1] - n0
+                assert (ran > 0) == (sw == "1"), (lengths, sw, ran)
+            finally:
+                eng.close()
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b), lengths
+
+
+@pytest.mark.gpu
 def test_conv_step_counter_timeout_fails_the_call(monkeypatch):
     """The fp32 / bf16x3 conv kernels replace the per-ci-tile barrier by an LDS step counter that a wave polls with a
     bound (conv_mfma.hip, LDS3).  A wave whose bound runs out goes on (every wave must reach the end of the grid) and may

@@ -71,6 +71,9 @@
 #ifndef K82_N32_HTN
 #define K82_N32_HTN 2               // MFMA tiles along t per wave in the 32-row fp32 shape (conv_post, the F0 / N heads): 2 = 256-column workgroup tiles
 #endif
+#ifndef K82_SMALL_OCC
+#define K82_SMALL_OCC 2             // persistent workgroups per CU of the fp32 small-launch (64 x 64 tile) kernels
+#endif
 #ifndef K82_OCC_SPLIT
 #define K82_OCC_SPLIT 2             // the bf16x3 kernels carry twice the A fragments: 3 per CU spills
 #endif
@@ -122,7 +125,8 @@ __device__ __forceinline__ float snake(float v, float al, float ial) {
 //   EPI_RES    y = (f(acc + bias) + res) * out_scale                         + float4 residual loads
 //   EPI_ACC    as EPI_RES, then accbuf = (acc_init ? 0 : accbuf) + y * acc_scale; y optional
 //   EPI_SCALAR transposed-conv phase interleave (up_s) / x2 nearest residual (res_shift): dword path
-enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3 };
+//   EPI_PART   split-K: the raw sum of ONE K block goes to ConvP::part (no bias, no epilogue); splitk_reduce_kernel finishes
+enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_ACC = 2, EPI_SCALAR = 3, EPI_PART = 4 };
 // sum over the 8 lanes of a row span (lane & ~7 ... | 7) on the VALU's DPP path (no LDS round trips): the two quad
 // permutes (xor 1, xor 2), then row_half_mirror (lane i <-> 7 - i, the other quad of the eight)
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
@@ -807,6 +811,23 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
         }
     };
     auto epilogue = [&](const Tile& T, float bias_l) {
+        if constexpr (EPI == EPI_PART) {                       // split-K: this workgroup's block sum, as it is
+            (void)bias_l;
+            const int z = (int)blockIdx.x % p.nblk;
+            float* pb = p.part + ((long)(z * p.B + T.b) * p.cout_p) * p.ppitch;
+#pragma unroll
+            for (int mi = 0; mi < HT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < HTN; ++ni) {
+                    const int t = T.n0 + nw + ni * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = T.m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        if (t < T.Lout) pb[(long)m * p.ppitch + t] = acc[mi][ni][r];
+                    }
+                }
+            return;
+        }
         bsh[lane] = bias_l;
         if constexpr (YB) {
             epilogue_b16(T, epi_args());
@@ -1151,12 +1172,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
     // Tile walk start.  (An XCD-aware renumbering -- the 64 workgroups of one XCD, b % 8, walking consecutive
     // tiles so halo and shared x tiles stay behind one L2 -- measured 1-6 % SLOWER on the same box than this
     // round-robin order, which spreads neighbouring tiles over all eight L2s and memory channels; kept simple.)
-    int q = next_valid(blockIdx.x, cur);
+    // split-K (EPI_PART): one (tile, K block) per workgroup, blockIdx = tile * nblk + block; the tile walk ends after it
+    // (q + G >= total).  it0 / it1: the staged ci-tiles of this workgroup's block.
+    constexpr bool PART = EPI == EPI_PART;
+    const int tpb = PART ? p.kflush * 16 / KC : ntiles;
+    const int it0 = PART ? ((int)blockIdx.x % p.nblk) * tpb : 0;
+    const int it1 = PART ? min(ntiles, it0 + tpb) : ntiles;
+    int q = next_valid(PART ? (int)blockIdx.x / p.nblk : (int)blockIdx.x, cur);
     if (q < 0) return;
     if (LDS3 && tid == 0) *stepcnt = 0u;
-    load_tile(cur, 0);
-    write_tile(cur, 0, lds);
-    load_a(cur.m0, 0, cur.tap0, a0);
+    load_tile(cur, it0 * KC);
+    write_tile(cur, it0 * KC, lds);
+    load_a(cur.m0, it0 * KC, cur.tap0, a0);
     __syncthreads();
     int g = 0;                                   // ci-tile steps done: buffer g % NBUF holds the current ci-tile
     int bcur = 0, bnxt = 1;
@@ -1173,9 +1200,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             const unsigned mm = (t >= 31) ? 0u : (cur.mask >> (t + 1));
             return mm ? t + 1 + __builtin_ctz(mm) : cur.tap0;
         };
-        for (int it = 0; it < ntiles; ++it) {
+        for (int it = it0; it < it1; ++it) {
             const int ci0 = it * KC;
-            const bool more = it + 1 < ntiles;
+            const bool more = it + 1 < it1;
             const float* xsb = lds + bcur * (KC * WP);
             float* xsn = lds + bnxt * (KC * WP);
             Tile S;                                           // whose x tile / weights come next (by value:
@@ -1184,7 +1211,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
             S.Lin = more ? cur.Lin : nxt.Lin;
             S.tbase = more ? cur.tbase : nxt.tbase;
             S.tap0 = more ? cur.tap0 : nxt.tap0;
-            const int sci0 = more ? ci0 + KC : 0;
+            const int sci0 = more ? ci0 + KC : it0 * KC;      // (PART: it0 of the same block -- a valid address, the tile is not used)
             // The taps of one ci-tile ping-pong between the two fragment sets: even steps compute from a0 while
             // the loads of the next step fill a1, odd steps the other way round -- no register rotation per tap
             // (16 v_mov, each of which costs the SIMD ~10 cycles that the partner wave's MFMAs do not cover) and no
@@ -1318,6 +1345,79 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : TAPS > 0 ? (HT * HT
 }
 
 #define REQUIRE_SNAKE_FREE(p) do { if ((p).act == ACT_SNAKE) { fprintf(stderr, "k82: Snake conv with <= 32 output channels is not built\n"); return; } } while (0)
+// split-K, second step: y = epilogue(b_0 + b_1 + ... in block order) -- the operations of the conv kernel's own epilogue on
+// the value its blocked summation (KSPLIT) would have left in the accumulator, so the two paths give the same bits
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvP p) {
+    const int b = blockIdx.z, m = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.lout.len(b)) return;
+    const float* pp = p.part + ((long)b * p.cout_p + m) * p.ppitch + t;
+    const long zs = (long)p.B * p.cout_p * p.ppitch;
+    float r = pp[0];
+    for (int z = 1; z < p.nblk; ++z) r += pp[z * zs];
+    float u = r + p.bias[m];
+    if (p.out_act == OACT_GELU_NEW) u = gelu_new(u);
+    if (p.res) u += p.res[(long)b * p.rbs + (long)m * p.rpitch + t];
+    u *= p.out_scale;
+    p.y[(long)b * p.ybs + (long)m * p.ypitch + t] = u;
+}
+// The same for launches whose epilogue also leaves instance-norm partials (ConvP::stat) or that are wide enough for 16-byte
+// accesses: a thread owns four consecutive columns, eight lanes a 32-column span -- the lane layout of the conv kernel's wide
+// epilogues, so the partials (4 sequential adds per lane, then sum8) are the bits that epilogue writes.
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(ConvP p) {
+    const int b = blockIdx.z, m = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int t = (blockIdx.x * 64 + lane) * 4, L = p.lout.len(b);
+    if (m >= p.cout) return;                                    // wave-uniform
+    const bool live = t < L;
+    const int tc = live ? t : 0;
+    const float* pp = p.part + ((long)b * p.cout_p + m) * p.ppitch + tc;
+    const long zs = (long)p.B * p.cout_p * p.ppitch;
+    float4 r = *reinterpret_cast<const float4*>(pp);
+    for (int z = 1; z < p.nblk; ++z) {
+        const float4 a = *reinterpret_cast<const float4*>(pp + z * zs);
+        r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+    }
+    const float bs = p.bias[m];
+    float v[4] = {r.x, r.y, r.z, r.w};
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.res) { const float4 u = *reinterpret_cast<const float4*>(p.res + (long)b * p.rbs + (long)m * p.rpitch + tc); rs[0] = u.x; rs[1] = u.y; rs[2] = u.z; rs[3] = u.w; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float u = v[e] + bs;
+        if (p.out_act == OACT_GELU_NEW) u = gelu_new(u);
+        if (p.res) u += rs[e];
+        u *= p.out_scale;
+        v[e] = u;
+    }
+    if (p.stat) {                                               // uniform
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = (live && t + e < L) ? v[e] : 0.f;
+            s1 += u;
+            s2 = fmaf(u, u, s2);
+        }
+        s1 = sum8(s1);
+        s2 = sum8(s2);
+        if ((lane & 7) == 0 && live) p.stat[(long)b * p.sbs + (long)m * p.snt + (t >> 5)] = make_float2(s1, s2);
+    }
+    if (live) *reinterpret_cast<float4*>(p.y + (long)b * p.ybs + (long)m * p.ypitch + t) = make_float4(v[0], v[1], v[2], v[3]);
+}
+// K blocks a small fp32 launch is split into (0: not split).  The conditions are those under which launch_conv would take the
+// 64 x 64-tile kernels WITH blocked summation, plus: few enough tiles that the chip is mostly idle, a plain or residual epilogue.
+int conv_splitk_blocks(const ConvP& p) {
+    if (p.wb || p.cout_p % 128 != 0 || p.act == ACT_SNAKE || p.kflush <= 0 || p.tapmask || p.up_s || p.res_shift || p.accbuf || !p.y) return 0;
+    if (p.cin_p <= 16 * p.kflush) return 0;
+    const unsigned cus = p.cus > 0 ? (unsigned)p.cus : 256u;
+    const long total = (long)((p.Lmax_out + 127) / 128) * (p.cout_p / 128) * p.B;
+    static const long small_env = [] { const char* e = getenv("K82_SMALL_GRID"); return e ? atol(e) : -1L; }();
+    const long small_grid = small_env >= 0 ? small_env : (long)K82_SMALL_GRID * cus / 256;
+    if (!(total < small_grid || p.Lmax_out <= 64)) return 0;
+    const long t64 = (long)((p.Lmax_out + 63) / 64) * (p.cout_p / 64) * p.B;
+    if (t64 > (long)cus) return 0;
+    const int kc16 = (p.taps == 1) ? 2 : 1;                    // the 1-tap small-launch kernel stages 32 channels per tile
+    if ((p.kflush % kc16) != 0) return 0;
+    return (p.cin_p / 16 + p.kflush - 1) / p.kflush;
+}
 static std::atomic<long> g_shape_launches[CONV_NSHAPE];
 long conv_shape_launches(int shape) { return shape >= 0 && shape < CONV_NSHAPE ? g_shape_launches[shape].load() : -1; }
 static inline unsigned ncu(const ConvP& p) { return p.cus > 0 ? (unsigned)p.cus : 256u; }
@@ -1491,7 +1591,21 @@ void launch_conv(const ConvP& p, hipStream_t s) {
             // the book workloads spend a fifth of their time in phase 1 on exactly these.  Same bits either way.)
             // too few 128 x 128 tiles to occupy the chip: 64 x 64 tiles (32 x 32 per wave), four times as many
             const long t64 = (long)((p.Lmax_out + 63) / 64) * (p.cout_p / 64) * p.B;
-            const unsigned grid = (unsigned)(t64 < kMaxBlocks ? t64 : kMaxBlocks);
+            // workgroups per CU of the 64 x 64-tile kernels: they hold 16 accumulator registers and 44 KB of LDS, so more than
+            // two are resident per CU, and a launch of slightly more tiles than 2 x CUs does not pay for a second, almost
+            // empty round of the tile walk (K82_SMALL_OCC: tuning only)
+            static const long small_occ = [] { const char* e = getenv("K82_SMALL_OCC"); return e ? atol(e) : (long)K82_SMALL_OCC; }();
+            const long cap64 = (long)cus * (small_occ > 0 ? small_occ : 2);
+            const unsigned grid = (unsigned)(t64 < cap64 ? t64 : cap64);
+            if (p.part && p.nblk >= 2) {                          // split-K: (tile, K block) per workgroup, then the ordered sum + epilogue
+                const unsigned g2 = (unsigned)(t64 * p.nblk);
+                if (p.taps == 1) hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 1, EPI_PART, false, PREC_F32, 32>), dim3(g2), dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 1, EPI_PART, false, PREC_F32, 16>), dim3(g2), dim3(256), 0, s, p);
+                if (p.stat) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((p.Lmax_out + 255) / 256, (p.cout + 3) / 4, p.B), dim3(256), 0, s, p);
+                else hipLaunchKernelGGL(splitk_reduce_kernel, dim3((p.Lmax_out + 255) / 256, p.cout, p.B), dim3(256), 0, s, p);
+                ++g_shape_launches[CONV_SHAPE_SPLITK];
+                return;
+            }
             if (p.taps == 1 && (epi == EPI_PLAIN || epi == EPI_RES)) launch_shape<2, 2, 1, 32>(p, epi, grid, s);
             else launch_shape<2, 2, 1>(p, epi, grid, s);
             ++g_shape_launches[CONV_SHAPE_LDS3];

@@ -222,6 +222,10 @@ struct k82_handle : K82Weights {
     int cus = 0;
     bool ring_off = false;             // K82_RING=0: the bf16 modes keep the generic tap loop (A/B and bit-identity tests only)
     bool bm256_off = false;            // K82_BM256=0: no 256 x 128 workgroup tiles (bit-identity tests only)
+    bool dec_zone = false;             // decode() is inside the decoder (AdainResBlk1d stack), before the generator
+    bool dec_ksplit = true;            // K82_DEC_KSPLIT=0: no blocked summation / split-K in the decoder (A/B)
+    bool splitk_on = true;             // K82_SPLITK=0: no split-K for small launches (A/B and bit-identity tests)
+    float* skbuf = nullptr; size_t skcap = 0;   // split-K block sums: one fixed workspace per handle (floats)
     bool t1_b16 = true;                // K82_T1_BF16=0: the bf16 mode keeps the resblock-internal tensor t1 in fp32 in HBM (A/B and bit-identity tests)
     bool fused_stats = true;           // K82_FUSED_STATS=0: every instance-norm statistic from the sweep kernel (A/B only)
     int lstm_split_max_b = 0;          // set in finalize(): CUs / 2 (K82_LSTM_SPLIT_MAX_B=0 selects the streaming kernel everywhere)
@@ -658,6 +662,8 @@ struct k82_handle : K82Weights {
             if (const char* e = std::getenv("K82_FUSED_STATS")) fused_stats = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_RING")) ring_off = std::atoi(e) == 0;
             if (const char* e = std::getenv("K82_T1_BF16")) t1_b16 = std::atoi(e) != 0;
+            if (const char* e = std::getenv("K82_SPLITK")) splitk_on = std::atoi(e) != 0;
+            if (const char* e = std::getenv("K82_DEC_KSPLIT")) dec_ksplit = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_KSPLIT")) precise = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_BM256")) bm256_off = std::atoi(e) == 0;
             // K82_LSTM_SPLIT_MAX_B=0: streaming kernel everywhere -- for deployments that KNOW the GPU is shared
@@ -668,6 +674,9 @@ struct k82_handle : K82Weights {
         lstm_err = (int*)wmalloc(2 * sizeof(int));
         conv_err = lstm_err + 1;
         HIPCHK(hipMemset(lstm_err, 0, 2 * sizeof(int)));
+        // split-K launches have at most CUs 64 x 64 tiles and at most 16 K blocks (the k = 5 text-encoder convs)
+        skcap = (size_t)cus * 4096 * 16;
+        skbuf = (float*)wmalloc(skcap * sizeof(float));
         host.clear();
         finalized = true;
     }
@@ -693,7 +702,9 @@ struct k82_handle : K82Weights {
         p.cus = cus; p.spin_limit = conv_spin_limit; p.err = conv_err;
         // blocked summation on every fp32 layer outside the decoder / generator (durations, F0 / N, text encoder): fold every
         // ~256 products (conv_mfma.hip KSPLIT).  16 / taps 16-channel tiles, kept even for the 32-channel small-launch tiles.
-        p.kflush = (precise && !bf16_zone) ? std::max(2, (16 / std::max(1, w.taps)) & ~1) : 0;
+        // ... and, in the fp32 mode, on the decoder's 1024-channel convs (K up to 3312): a single sentence's decoder launches are
+        // then split over K blocks like the token-rate ones (run_conv), and a batch sums the same blocks in one workgroup
+        p.kflush = (precise && (!bf16_zone || (dec_zone && precision == 0 && dec_ksplit))) ? std::max(2, (16 / std::max(1, w.taps)) & ~1) : 0;
         return p;
     }
     // operand shapes the kernel and its grid assume (conv_mfma.hip launch_conv), checked before every launch
@@ -720,7 +731,14 @@ struct k82_handle : K82Weights {
         REQUIRE((long)p.cout_p * p.ypitch < kMaxElems && (long)p.cout_p * p.rpitch < kMaxElems && (long)p.cout_p * p.apitch < kMaxElems &&
                 (!p.stat || (long)p.cout_p * p.snt < (kMaxElems >> 1)), K82_EINVAL, "conv output of one sentence exceeds 4 GB");
     }
-    void run_conv(const ConvP& p, const int* host_base) {
+    void run_conv(const ConvP& p0, const int* host_base) {
+        ConvP p = p0;
+        // small launches of the token-rate / prosody layers (a single sentence, a short batch): split over K blocks -- same bits
+        if (splitk_on && skbuf) {
+            const int nblk = conv_splitk_blocks(p);
+            const int pp = ru(p.Lmax_out, 4);
+            if (nblk >= 2 && (size_t)nblk * p.B * p.cout_p * pp <= skcap) { p.part = skbuf; p.nblk = nblk; p.ppitch = pp; }
+        }
         check_conv(p);
         const int fam = (p.cout_p % 128 == 0) ? FAM_CONV22 : FAM_CONV14;
         double work = 0;
@@ -1107,9 +1125,10 @@ struct k82_handle : K82Weights {
         // bf16 MFMA mode (k82_set_precision): from here on -- decoder and generator convs -- the 2x2-shaped
         // convs take their bf16 weight image; everything before (durations, F0/N curves, text encoder) and
         // conv_post (1x4 shape) stay on the exact-fp32 instruction.  The guard clears the flag on any exit.
-        struct Bf16Scope { bool& f; bool& z; ~Bf16Scope() { f = false; z = false; } } bf16_scope{bf16_now, bf16_zone};
+        struct Bf16Scope { bool& f; bool& z; bool& d; ~Bf16Scope() { f = false; z = false; d = false; } } bf16_scope{bf16_now, bf16_zone, dec_zone};
         bf16_now = precision != 0;
         bf16_zone = true;
+        dec_zone = true;
         resblk1d(enc, cat0, c0bs, PF, lF, Fmax, hb, sumF, catA, c1bs, PF, gbd, Gd, aF);
         tap("dec_encode", catA, 1024, PF, c1bs, nb);
         for (float* cat : {catA, catB}) {
@@ -1122,6 +1141,7 @@ struct k82_handle : K82Weights {
         float* xdec = aF.f((size_t)nb * 512 * P2);
         resblk1d(dec[3], catB, c1bs, PF, lF, Fmax, hb, sumF, xdec, (long)512 * P2, P2, gbd, Gd, aF);
         tap("dec_out", xdec, 512, P2, (long)512 * P2, nb);
+        dec_zone = false;
 
         // ---- harmonic source + STFT (rows a14, a15)
         float* ph = aF.f((size_t)nb * K82_HARM * P2);
@@ -1309,6 +1329,8 @@ int k82_fork(k82_handle* parent, k82_handle** out) {
         static_cast<K82Weights&>(*h) = static_cast<const K82Weights&>(*parent);
         h->scratch = parent->scratch;
         h->cus = parent->cus;
+        h->dec_ksplit = parent->dec_ksplit; h->splitk_on = parent->splitk_on; h->skcap = parent->skcap;
+        h->skbuf = (float*)h->wmalloc(h->skcap * sizeof(float));
         h->t1_b16 = parent->t1_b16; h->ring_off = parent->ring_off; h->bm256_off = parent->bm256_off; h->fused_stats = parent->fused_stats; h->precise = parent->precise;
         h->lstm_split_max_b = parent->lstm_split_max_b; h->lstm_spin_limit = parent->lstm_spin_limit; h->conv_spin_limit = parent->conv_spin_limit;
         h->precision = parent->precision;
@@ -1454,7 +1476,7 @@ int k82_prof_read(k82_handle* h, const char* name, double* ms, int64_t* launches
         double m = 0, w = 0; int64_t n = 0; bool found = false;
         if (std::strcmp(name, "lstm_fallbacks") == 0) { n = h->lstm_fallbacks; found = true; }
         // launches of the large-tile conv families since the process started (bit-identity tests assert that they ran)
-        const char* const shapes[CONV_NSHAPE] = {"conv_shape_bm256", "conv_shape_ring_wn2", "conv_shape_ring", "conv_shape_lds3", "conv_shape_ksplit"};
+        const char* const shapes[CONV_NSHAPE] = {"conv_shape_bm256", "conv_shape_ring_wn2", "conv_shape_ring", "conv_shape_lds3", "conv_shape_ksplit", "conv_shape_splitk"};
         for (int i = 0; i < CONV_NSHAPE; ++i)
             if (std::strcmp(name, shapes[i]) == 0) { n = conv_shape_launches(i); found = true; }
         // workspace of the largest pass so far / capacity held now, in bytes (sizing of k82_reserve, tests)

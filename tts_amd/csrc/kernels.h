@@ -69,6 +69,11 @@ struct ConvP {
     int dbg;                                   // test switches of the engine: bit 0 = no ring pipeline (K82_RING=0), bit 1 = no 256 x 128 tiles (K82_BM256=0)
     int kflush;                                // > 0: blocked summation over K (fp32 kernels, conv_mfma.hip KSPLIT) -- the accumulator is folded
                                                // into a second one every kflush 16-channel tiles; 0: one sequential chain
+    // split-K (small fp32 launches with blocked summation, conv_mfma.hip EPI_PART): part != nullptr -- workgroup (tile, z) sums
+    // K block z (kflush 16-channel tiles) alone and stores the raw block sum at part[((z * B + b) * cout_p + m) * ppitch + t];
+    // splitk_reduce then adds the nblk block sums IN BLOCK ORDER and applies the epilogue: the bits of the one-workgroup kernel,
+    // whose K chain (one dependent global -> LDS -> MFMA step per 32 channels) is what a single sentence's Linears wait for.
+    float* part; int nblk, ppitch;
     int cus;                                   // compute units of the device (hipDeviceProp_t::multiProcessorCount): persistent grids and the
                                                // large-launch thresholds scale with it (0: 256, an unpartitioned MI355X)
     int spin_limit;                            // polls an LDS3 wave waits for its workgroup's step counter before it gives up (engine: 1 << 16)
@@ -84,7 +89,8 @@ void launch_conv(const ConvP& p, hipStream_t s);
 // launches of the large-tile families since the process started (tests assert that a bit-identity comparison really
 // ran them): 0 = 256 x 128 workgroup tiles (fp32 4 x 2 waves / bf16 modes 8 x 1 waves), 1 = bf16 ring 128 x 256 tiles (4 x 2 waves),
 // 2 = bf16 ring pipeline (any shape), 3 = LDS3 two-set kernels, 4 = blocked-summation (KSPLIT) kernels
-enum { CONV_SHAPE_BM256 = 0, CONV_SHAPE_RING_WN2 = 1, CONV_SHAPE_RING = 2, CONV_SHAPE_LDS3 = 3, CONV_SHAPE_KSPLIT = 4, CONV_NSHAPE = 5 };
+enum { CONV_SHAPE_BM256 = 0, CONV_SHAPE_RING_WN2 = 1, CONV_SHAPE_RING = 2, CONV_SHAPE_LDS3 = 3, CONV_SHAPE_KSPLIT = 4, CONV_SHAPE_SPLITK = 5, CONV_NSHAPE = 6 };
+int conv_splitk_blocks(const ConvP& p);                    // K blocks launch_conv would split this launch into if p.part were set (0: none)
 long conv_shape_launches(int shape);
 double conv_flops(const ConvP& p, const int* host_lens);   // algorithmic FLOPs of one launch
 

@@ -144,7 +144,12 @@ void launch_style_fc(const float* W, const float* bias, int rows, const float* r
 // value is loaded ONCE into registers (up to 48 per thread, all loads independent), the 16 partial sums meet in
 // LDS.  Two-pass (mean, then centred variance) like the reference's layer_norm.  C <= 768 (checked by the launcher,
 // which falls back to the serial kernel below for anything larger).
-#define LN_MAXCH 48
+// NI = C / 16 is a template parameter (48: ALBERT, 32: AdaLN / text encoder): no channel-validity test anywhere, and the
+// loads are issued as BLOCKS in front of a scheduling barrier.  (Written as one loop -- load, add, next -- the compiler
+// waited for every load before it issued the next one, and again for every gain / offset pair in the store loop: 96
+// sequential L2 round trips, 27 us for a kernel that moves 120 KB; a tenth of a single sentence's latency.)  Same
+// operations in the same order as that loop: same bits.
+template <int NI>
 __global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, const float* res, float* y, long bs,
                                                              long ybs, int pitch, LenSpec ls, int C, float eps, const float* w,
                                                              const float* bias, const float* gb, int gbstride,
@@ -155,19 +160,27 @@ __global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, co
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < L;
     const int tc = ok ? t : 0;                               // clamped: every lane loads, only valid lanes store
-    const float* xc = x + ls.base(b, bs) + tc;
-    const float* rc = res ? res + ls.base(b, bs) + tc : xc;
-    const float rmul = res ? 1.f : 0.f;
-    float v[LN_MAXCH];
+    const float* xc = x + ls.base(b, bs) + tc + (long)wv * pitch;
+    const long cstep = (long)16 * pitch;
+    float v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = xc[i * cstep];
+    __builtin_amdgcn_sched_barrier(0);
+    if (res) {                                               // (uniform; no caller passes a residual today)
+        const float* rc = res + ls.base(b, bs) + tc + (long)wv * pitch;
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += 16) {
+            float r[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r[k] = rc[(i0 + k) * cstep];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[i0 + k] = v[i0 + k] + r[k];
+        }
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        const int c = wv + 16 * i;
-        const int cc = c < C ? c : 0;
-        const float u = xc[(long)cc * pitch] + rmul * rc[(long)cc * pitch];
-        v[i] = c < C ? u : 0.f;
-        s += v[i];
-    }
+    for (int i = 0; i < NI; ++i) s += v[i];
     red[0][wv][lane] = s;
     __syncthreads();
     float tot = 0.f;
@@ -176,10 +189,10 @@ __global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, co
     const float mean = tot / C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        const float d = (wv + 16 * i < C) ? v[i] - mean : 0.f;
+    for (int i = 0; i < NI; ++i) {
+        const float d = v[i] - mean;
         v[i] = d;
-        q += d * d;
+        q = fmaf(d, d, q);
     }
     red[1][wv][lane] = q;
     __syncthreads();
@@ -187,17 +200,27 @@ __global__ __launch_bounds__(1024) void layernorm_cols_kernel(const float* x, co
 #pragma unroll
     for (int k = 0; k < 16; ++k) qt += red[1][k][lane];
     const float rstd = 1.0f / sqrtf(qt / C + eps);
-    float* yc = y + ls.base(b, ybs) + tc;
-    const float* g = gb ? gb + (long)b * gbstride + goff : nullptr;
+    float* yc = y + ls.base(b, ybs) + tc + (long)wv * pitch;
+    // gain / offset of channel c: (1 + gamma, beta) of the AdaLN style row or (w, bias), through pointers chosen once
+    // (0 + w == w and a * b == b * a exactly: the bits of the two-branch form)
+    const float* gp = (gb ? gb + (long)b * gbstride + goff : w) + wv;
+    const float* bp = (gb ? gb + (long)b * gbstride + goff + C : bias) + wv;
+    const float gadd = gb ? 1.0f : 0.0f;
+    const float lk = leaky;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        const int c = wv + 16 * i;
-        if (c < C) {                                         // wave-uniform
-            float o = v[i] * rstd;
-            if (g) o = (1.0f + g[c]) * o + g[C + c];
-            else o = o * w[c] + bias[c];
-            if (leaky != 1.0f) o = o < 0.f ? o * leaky : o;
-            if (ok) yc[(long)c * pitch] = o;
+    for (int i0 = 0; i0 < NI; i0 += 16) {
+        float ga[16], be[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ga[k] = gp[16 * (i0 + k)]; be[k] = bp[16 * (i0 + k)]; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float o = v[i0 + k] * rstd;
+                o = fmaf(gadd + ga[k], o, be[k]);             // (spelled out: left to contraction, the packed form of this loop was not fused)
+                o = (lk != 1.0f && o < 0.f) ? o * lk : o;
+                yc[(i0 + k) * cstep] = o;
+            }
         }
     }
 }
@@ -232,8 +255,11 @@ __global__ __launch_bounds__(64) void layernorm_cols_serial_kernel(const float* 
 void launch_layernorm_cols(const float* x, const float* res, float* y, long bs, long ybs, int pitch, LenSpec ls, int C,
                            int B, int Tmax, float eps, const float* w, const float* bias, const float* gb,
                            int gbstride, int goff, float leaky, hipStream_t s) {
-    if (C <= 16 * LN_MAXCH)
-        hipLaunchKernelGGL(layernorm_cols_kernel, dim3(DIVUP(Tmax, 64), B), dim3(1024), 0, s, x, res, y, bs, ybs, pitch, ls,
+    if (C == 768)
+        hipLaunchKernelGGL(layernorm_cols_kernel<48>, dim3(DIVUP(Tmax, 64), B), dim3(1024), 0, s, x, res, y, bs, ybs, pitch, ls,
+                           C, eps, w, bias, gb, gbstride, goff, leaky);
+    else if (C == 512)
+        hipLaunchKernelGGL(layernorm_cols_kernel<32>, dim3(DIVUP(Tmax, 64), B), dim3(1024), 0, s, x, res, y, bs, ybs, pitch, ls,
                            C, eps, w, bias, gb, gbstride, goff, leaky);
     else
         hipLaunchKernelGGL(layernorm_cols_serial_kernel, dim3(DIVUP(Tmax, 64), B), dim3(64), 0, s, x, res, y, bs, ybs, pitch,
