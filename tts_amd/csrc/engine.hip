@@ -667,7 +667,7 @@ struct k82_handle : K82Weights {
             if (const char* e = std::getenv("K82_KSPLIT")) precise = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_BM256")) bm256_off = std::atoi(e) == 0;
             // K82_LSTM_SPLIT_MAX_B=0: streaming kernel everywhere -- for deployments that KNOW the GPU is shared
-            if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::min(lstm_split_max_b, std::atoi(e));
+            if (const char* e = std::getenv("K82_LSTM_SPLIT_MAX_B")) lstm_split_max_b = std::max(0, std::min(4 * cus, std::atoi(e)));   // (above CUs / 2: rounds of the split grid; tuning)
             if (const char* e = std::getenv("K82_LSTM_SPIN_LIMIT")) lstm_spin_limit = std::max(0, std::atoi(e));   // test hook
         }
         if (const char* e = std::getenv("K82_CONV_SPIN_LIMIT")) conv_spin_limit = std::max(0, std::atoi(e));   // test hook
