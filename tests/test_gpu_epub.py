@@ -185,3 +185,37 @@ def test_two_contexts_overlap_phases_and_keep_every_bit(engine):
     finally:
         two.close()
     assert len(two.engines) == 1 and not engine._forks
+
+
+def test_art_of_war_whole_book_bf16_sharded_properties(engine):
+    """BASELINE configs[2] at FULL size on one GPU: every sentence of The Art of War (5.8 k sentences, ~14 h of audio) in
+    the bf16 mode through BatchSynthesizer, then again as the 2-way shard tools/bench_book_dp.py would run on two GPUs.
+    Size-independent properties: every waveform finite and exactly 600 x sum(pred_dur) samples, every duration >= 1,
+    and the union of the two shards reproduces the unsharded pass bit for bit (other batches, other padding, other
+    launch shapes -- same samples).  The oracle comparison lives in test_art_of_war_bf16_sharded (first 300 sentences)."""
+    sents = [t for _, t in _book("epub_art_of_war.json.gz")["sentences"]]
+    ids = _ids_of(sents)
+    n = len(ids)
+    assert n > 5000
+    pack = spec.synthetic_voice_pack(1)
+    rows = [T.style_row(pack, len(x), "kokoro_onnx") for x in ids]
+    seeds = [20000 + i for i in range(n)]
+    syn = BatchSynthesizer(engine, max_batch=256)
+    engine.set_precision("bf16")
+    try:
+        whole = syn.synthesize(ids, rows, seeds=seeds)
+        parts = shard_sentences([len(x) + 2 for x in ids], 2)
+        assert sorted(parts[0] + parts[1]) == list(range(n))
+        total = 0
+        for p in parts:
+            shard = syn.synthesize(ids, rows, seeds=seeds, indices=p)
+            assert sorted(shard) == p
+            for i in p:
+                a, d = whole[i]
+                assert d.min() >= 1 and a.size == 600 * int(d.sum()) and np.isfinite(a).all(), i
+                assert np.array_equal(d, shard[i][1]) and np.array_equal(a, shard[i][0]), i
+                total += a.size
+            del shard
+    finally:
+        engine.set_precision("fp32")
+    print(f"The Art of War, {n} sentences, bf16: {total / 24000 / 3600:.1f} h of audio; 2-way shard bit-identical")
