@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   shift; i=0
   for F in "$@"; do
     d=/tmp/ab_$i; rm -rf $d; mkdir -p $d
-    for f in conv_mfma ops engine; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $F -c tts_amd/csrc/$f.hip -o $d/$f.o & done
+    for f in conv_mfma conv_ring ops engine; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $F -c tts_amd/csrc/$f.hip -o $d/$f.o & done
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $F -c tts_amd/csrc/source.hip -o $d/source.o
     wait
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tts_amd/libk82_v$i.so $d/*.o

@@ -2,7 +2,7 @@
 # Resource usage (VGPRs, scratch, spilled SGPRs, occupancy) of every conv_mfma_kernel instantiation, one line each.
 # usage: tools/kernel_resources.sh [extra hipcc flags]  > table
 cd "$(dirname "$0")/../tts_amd/csrc" || exit 1
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage "$@" -c conv_mfma.hip -o /tmp/k82_res.o 2>&1 |
+for f in conv_mfma conv_ring; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage "$@" -c $f.hip -o /tmp/k82_res_$f.o 2>&1; done |
 python3 -c '
 import re, sys
 cur = None
