@@ -5,7 +5,10 @@
 bool launch_ring_bf16(const ConvP& p, int epi, long total, hipStream_t s) {
     constexpr int PREC = PREC_BF16;
     // the ring pipeline: all taps active, a compile-time tap count, at least two ci-tiles (see the kernel)
-    if ((p.dbg & 1) || p.tapmask || p.cin_p < 32 || (p.cin % 16 != 0 && !(p.cin_pad_ok && p.tr == TR_NORM && K82_RING_SMEM))) return false;   // (cin % 16: the staging reads its parameters per channel PAIR)   // dbg = 1: K82_RING=0 (A/B switch of the engine)
+    // (a tap mask -- the transposed convs' phase rows, two of three taps non-zero per 64-row tile -- is simply ignored: the masked
+    // taps' weights are exact zeros, so the ring's all-taps loop adds 0 x finite = 0 to the accumulators: same values as the
+    // generic loop that skips them, at 1.5x the MFMAs of a kernel that runs 2.5x as fast on these launches)
+    if ((p.dbg & 1) || (p.tapmask && (p.taps != 3 || p.act == ACT_SNAKE)) || p.cin_p < 32 || (p.cin % 16 != 0 && !(p.cin_pad_ok && p.tr == TR_NORM && K82_RING_SMEM))) return false;   // (cin % 16: the staging reads its parameters per channel PAIR)   // dbg = 1: K82_RING=0 (A/B switch of the engine)
     const bool snake = p.act == ACT_SNAKE;
     if (snake && epi == EPI_SCALAR) return false;
     // (Measured and not kept: 4 x 1 waves of 32 x 256 at one workgroup per CU -- weight traffic halves again, but with one
