@@ -333,3 +333,79 @@ def test_second_phase_rebucketing_by_predicted_frames():
     eng2 = FakeEngine()
     BatchSynthesizer(eng2, frame_pad_limit=float("inf")).synthesize(id_lists, rows)
     assert len(eng2.decoded) == 1
+
+
+def test_batches_over_several_contexts_host_logic():
+    """scheduler.BatchSynthesizer(contexts=N): one host thread per execution context (Engine.fork), batches handed out in
+    order, results by sentence index -- the host logic without a GPU: a fake engine whose forks record what they ran.
+    Every sentence gets ITS audio whatever context ran its batch, every context worked, the stats add up, a failing
+    context's exception reaches the caller, and close() destroys the forks."""
+    import contextlib
+    import threading
+    import time
+    from tts_amd.scheduler import BatchSynthesizer
+
+    class FakeEngine:
+        def __init__(self, parent=None, fail_on=None):
+            self.parent, self.forks, self.ran, self.closed, self.fail_on = parent, [], [], False, fail_on
+            self._lock = threading.RLock()
+
+        def fork(self):
+            f = FakeEngine(self, self.fail_on)
+            self.forks.append(f)
+            return f
+
+        def close(self):
+            self.closed = True
+
+        @contextlib.contextmanager
+        def session(self):
+            with self._lock:
+                yield self
+
+        @staticmethod
+        def pack(id_lists):
+            lens = np.array([len(x) + 2 for x in id_lists], np.int32)
+            ids = np.zeros((len(id_lists), int(lens.max())), np.int64)
+            for b, x in enumerate(id_lists):
+                ids[b, 1:1 + len(x)] = x
+            return ids, lens
+
+        def durations(self, ids, lens, ref_s, speed=None):
+            if self.fail_on is not None and self.fail_on in ids[:, 1]:
+                raise RuntimeError("k82 error -5: injected")
+            pred = np.zeros(ids.shape, np.int32)
+            pred[:, 1] = 2
+            self._tag = ids[:, 1].copy()
+            time.sleep(0.01)                                    # long enough for the other contexts to take batches
+            return pred, pred.sum(axis=1).astype(np.int64)
+
+        def decode(self, seeds=None):
+            self.ran.append((threading.current_thread().name, tuple(int(t) for t in self._tag)))
+            off = np.arange(len(self._tag) + 1, dtype=np.int64) * 1200
+            return np.repeat(self._tag.astype(np.float32), 1200), off
+
+    n = 60
+    id_lists = [[100 + i] + [7] * (3 + i % 40) for i in range(n)]     # first id = the sentence's tag; several token buckets
+    rows = [np.zeros(256, np.float32)] * n
+    with pytest.raises(ValueError):
+        BatchSynthesizer(FakeEngine(), contexts=0)
+    one = BatchSynthesizer(FakeEngine(), max_batch=4)
+    eng = FakeEngine()
+    three = BatchSynthesizer(eng, max_batch=4, contexts=3)
+    assert len(three.engines) == 3 and three.engines[0] is eng and len(eng.forks) == 2
+    a, b = one.synthesize(id_lists, rows), three.synthesize(id_lists, rows)
+    assert sorted(a) == sorted(b) == list(range(n))
+    for i in range(n):
+        assert np.array_equal(a[i][0], b[i][0]) and (b[i][0] == 100 + i).all() and np.array_equal(a[i][1], b[i][1])
+    assert all(e.ran for e in three.engines)                            # every context took batches
+    assert {name for e in three.engines for name, _ in e.ran} == {"k82-context-0", "k82-context-1", "k82-context-2"}
+    assert sorted(t for e in three.engines for _, tags in e.ran for t in tags) == [100 + i for i in range(n)]
+    assert three.stats["batches"] == one.stats["batches"] == sum(len(e.ran) for e in three.engines)
+    assert three.stats["frames"] == one.stats["frames"] == 2 * n
+    three.close()
+    assert all(f.closed for f in eng.forks) and not eng.closed and len(three.engines) == 1
+    # a context that fails: the exception reaches the caller's thread
+    bad = BatchSynthesizer(FakeEngine(fail_on=117), max_batch=4, contexts=2)
+    with pytest.raises(RuntimeError, match="injected"):
+        bad.synthesize(id_lists, rows)
