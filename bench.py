@@ -221,7 +221,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_traffic(args, timeout_s=200):
+def measure_traffic(args, timeout_s=120):
     """roofline.traffic of THIS box: HBM bytes per launch of the dominant kernel family from the PMC counters, collected
     as MI355X_MICROARCH.md prescribes -- two separate child runs, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
     (nothing else on the command line), each over one step of this same workload (`--traffic-child`: one sizing pass
