@@ -223,6 +223,7 @@ struct k82_handle : K82Weights {
     bool ring_off = false;             // K82_RING=0: the bf16 modes keep the generic tap loop (A/B and bit-identity tests only)
     bool bm256_off = false;            // K82_BM256=0: no 256 x 128 workgroup tiles (bit-identity tests only)
     bool dec_zone = false;             // decode() is inside the decoder (AdainResBlk1d stack), before the generator
+    int kflush_div = 2;                // K82_KFLUSH_DIV (1, 2, 4): K blocks of 256 / div products.  2: a single sentence's split-K chains are half as long (p50 7.5 -> 7.2 ms); 4 gains nothing more
     bool dec_ksplit = true;            // K82_DEC_KSPLIT=0: no blocked summation / split-K in the decoder (A/B)
     bool splitk_on = true;             // K82_SPLITK=0: no split-K for small launches (A/B and bit-identity tests)
     float* skbuf = nullptr; size_t skcap = 0;   // split-K block sums: one fixed workspace per handle (floats)
@@ -664,6 +665,7 @@ struct k82_handle : K82Weights {
             if (const char* e = std::getenv("K82_T1_BF16")) t1_b16 = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_SPLITK")) splitk_on = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_DEC_KSPLIT")) dec_ksplit = std::atoi(e) != 0;
+            if (const char* e = std::getenv("K82_KFLUSH_DIV")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) kflush_div = v; }
             if (const char* e = std::getenv("K82_KSPLIT")) precise = std::atoi(e) != 0;
             if (const char* e = std::getenv("K82_BM256")) bm256_off = std::atoi(e) == 0;
             // K82_LSTM_SPLIT_MAX_B=0: streaming kernel everywhere -- for deployments that KNOW the GPU is shared
@@ -675,7 +677,7 @@ struct k82_handle : K82Weights {
         conv_err = lstm_err + 1;
         HIPCHK(hipMemset(lstm_err, 0, 2 * sizeof(int)));
         // split-K launches have at most CUs 64 x 64 tiles and at most 16 K blocks (the k = 5 text-encoder convs)
-        skcap = (size_t)cus * 4096 * 16;
+        skcap = (size_t)cus * 4096 * 16 * kflush_div;
         skbuf = (float*)wmalloc(skcap * sizeof(float));
         host.clear();
         finalized = true;
@@ -704,7 +706,7 @@ struct k82_handle : K82Weights {
         // ~256 products (conv_mfma.hip KSPLIT).  16 / taps 16-channel tiles, kept even for the 32-channel small-launch tiles.
         // ... and, in the fp32 mode, on the decoder's 1024-channel convs (K up to 3312): a single sentence's decoder launches are
         // then split over K blocks like the token-rate ones (run_conv), and a batch sums the same blocks in one workgroup
-        p.kflush = (precise && (!bf16_zone || (dec_zone && precision == 0 && dec_ksplit))) ? std::max(2, (16 / std::max(1, w.taps)) & ~1) : 0;
+        p.kflush = (precise && (!bf16_zone || (dec_zone && precision == 0 && dec_ksplit))) ? std::max(2, ((16 / kflush_div) / std::max(1, w.taps)) & ~1) : 0;
         return p;
     }
     // operand shapes the kernel and its grid assume (conv_mfma.hip launch_conv), checked before every launch
@@ -1329,7 +1331,7 @@ int k82_fork(k82_handle* parent, k82_handle** out) {
         static_cast<K82Weights&>(*h) = static_cast<const K82Weights&>(*parent);
         h->scratch = parent->scratch;
         h->cus = parent->cus;
-        h->dec_ksplit = parent->dec_ksplit; h->splitk_on = parent->splitk_on; h->skcap = parent->skcap;
+        h->kflush_div = parent->kflush_div; h->dec_ksplit = parent->dec_ksplit; h->splitk_on = parent->splitk_on; h->skcap = parent->skcap;
         h->skbuf = (float*)h->wmalloc(h->skcap * sizeof(float));
         h->t1_b16 = parent->t1_b16; h->ring_off = parent->ring_off; h->bm256_off = parent->bm256_off; h->fused_stats = parent->fused_stats; h->precise = parent->precise;
         h->lstm_split_max_b = parent->lstm_split_max_b; h->lstm_spin_limit = parent->lstm_spin_limit; h->conv_spin_limit = parent->conv_spin_limit;
