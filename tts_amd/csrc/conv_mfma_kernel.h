@@ -212,7 +212,7 @@ __device__ __forceinline__ floatx2 snake2(floatx2 v, float al, float ial) {     
 // products as ONE sequential fp32 chain, so its rounding noise grows like sqrt(K): measured against a float64 result
 // (tools/conv_noise.py) the kernel is as accurate as torch's CPU kernels up to K = 256 and 1.9x / 2.9x / 5.2x noisier at
 // K = 768 / 2048 / 3270, because those sum in blocks of a few hundred products.  With KSPLIT the running accumulator is
-// folded into a second one every ConvP::kflush 16-channel tiles (~256 products) and cleared; the output is the sum of
+// folded into a second one every ConvP::kflush 16-channel tiles (~128 products: engine.hip cp()) and cleared; the output is the sum of
 // the block sums.  The engine asks for it on the token-rate and prosody layers (ALBERT, duration / F0 / N predictors, text
 // encoder: < 3 % of the FLOPs), whose noise reaches the rounded durations and the F0 curve that the harmonic source
 // integrates into a phase.  Costs 16 * HT * HTN more registers and two vector instructions per accumulator and block.

@@ -703,7 +703,7 @@ struct k82_handle : K82Weights {
         p.dbg = (ring_off ? 1 : 0) | (bm256_off ? 2 : 0);
         p.cus = cus; p.spin_limit = conv_spin_limit; p.err = conv_err;
         // blocked summation on every fp32 layer outside the decoder / generator (durations, F0 / N, text encoder): fold every
-        // ~256 products (conv_mfma.hip KSPLIT).  16 / taps 16-channel tiles, kept even for the 32-channel small-launch tiles.
+        // ~128 products (conv_mfma_kernel.h KSPLIT).  (16 / kflush_div) / taps 16-channel tiles, kept even for the 32-channel small-launch tiles.
         // ... and, in the fp32 mode, on the decoder's 1024-channel convs (K up to 3312): a single sentence's decoder launches are
         // then split over K blocks like the token-rate ones (run_conv), and a batch sums the same blocks in one workgroup
         p.kflush = (precise && (!bf16_zone || (dec_zone && precision == 0 && dec_ksplit))) ? std::max(2, ((16 / kflush_div) / std::max(1, w.taps)) & ~1) : 0;
