@@ -23,7 +23,7 @@ for k, cs in acc.items():
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     n = len(cs["GRBM_GUI_ACTIVE"])
     cyc = m["GRBM_GUI_ACTIVE"] / 8
-    rows.append((cyc * n, f"{k[:62]:62s} launches={n:4d}  cycles/launch={cyc:12.0f}  "
+    rows.append((cyc * n, f"{k[:92]:92s} launches={n:4d}  cycles/launch={cyc:12.0f}  "
                  f"mfma_busy={100 * m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc:4.1f}%  "
                  f"wait_inst={100 * m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:4.1f}%"))
 for _, line in sorted(rows, reverse=True):
